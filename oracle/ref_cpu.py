@@ -1,0 +1,392 @@
+"""CPU oracle for the nested-diffusion (LaDiNE) inference hot path.
+
+TEST INFRASTRUCTURE ONLY.  This module is a CPU restatement (plain torch fp32 on the
+host) of the reference algorithm.  Only ``tests/``, ``__graft_entry__.smoke()`` and
+the ``cpu_baseline`` leg of ``bench.py`` may import it, and only as the checker /
+reported baseline -- never as the thing shipped.  The product path
+(``nested_diffusion_amd``) never imports this file and fails loudly when the HIP
+library is missing.
+
+Pinning: the sampler, the eps_theta network, the schedule tables, the mapping MLP and
+the aggregation functions are pinned against outputs of the reference itself, imported
+in the build container by ``tools/gen_golden.py`` (fixtures under ``tests/golden/``,
+checked by ``tests/test_oracle_golden.py``).  The ViT prefix (timm 0.4.12, third-party,
+source absent from /root/reference and not installed) is restated from timm 0.4.12's
+published ``vision_transformer.py`` semantics: PARITY UNPINNED for that one piece.
+
+All ``file:line`` citations are relative to /root/reference/.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+BN_EPS = 1e-5          # nn.BatchNorm1d default (diffusion/latent_model.py:129,155,162-166)
+LN_EPS = 1e-6          # timm 0.4.12 vit_base_patch16_224: partial(nn.LayerNorm, eps=1e-6)
+
+
+# ----------------------------------------------------------------------------
+# schedule  (diffusion/diffusion_utils.py:5-28; classification_train_separately.py:215-226)
+# ----------------------------------------------------------------------------
+def make_beta_schedule(schedule: str = "linear", num_timesteps: int = 1000,
+                       start: float = 1e-5, end: float = 1e-2) -> Tensor:
+    """diffusion/diffusion_utils.py:5-28 (all branches)."""
+    if schedule == "linear":
+        betas = torch.linspace(start, end, num_timesteps)
+    elif schedule == "const":
+        betas = end * torch.ones(num_timesteps)
+    elif schedule == "quad":
+        betas = torch.linspace(start ** 0.5, end ** 0.5, num_timesteps) ** 2
+    elif schedule == "jsd":
+        betas = 1.0 / torch.linspace(num_timesteps, 1, num_timesteps)
+    elif schedule == "sigmoid":
+        betas = torch.linspace(-6, 6, num_timesteps)
+        betas = torch.sigmoid(betas) * (end - start) + start
+    elif schedule in ("cosine", "cosine_reverse"):
+        max_beta, cosine_s = 0.999, 0.008
+        betas = torch.tensor([
+            min(1 - (math.cos(((i + 1) / num_timesteps + cosine_s) / (1 + cosine_s) * math.pi / 2) ** 2)
+                / (math.cos((i / num_timesteps + cosine_s) / (1 + cosine_s) * math.pi / 2) ** 2), max_beta)
+            for i in range(num_timesteps)])
+    elif schedule == "cosine_anneal":
+        betas = torch.tensor([
+            start + 0.5 * (end - start) * (1 - math.cos(t / (num_timesteps - 1) * math.pi))
+            for t in range(num_timesteps)])
+    else:
+        raise ValueError(schedule)
+    return betas
+
+
+def schedule_tables(schedule: str, num_timesteps: int, start: float, end: float):
+    """(alphas, one_minus_alphas_bar_sqrt) exactly as the runner derives them
+    (classification_train_separately.py:215-226): fp32 throughout, cumprod in fp32."""
+    betas = make_beta_schedule(schedule, num_timesteps, start, end).float()
+    alphas = 1.0 - betas
+    alphas_cumprod = alphas.cumprod(dim=0)
+    omabs = torch.sqrt(1 - alphas_cumprod)
+    if schedule == "cosine":
+        omabs = omabs * 0.9999
+    return alphas, omabs
+
+
+# ----------------------------------------------------------------------------
+# eps_theta network  (diffusion/latent_model.py:93-184, arch == 'linear')
+# ----------------------------------------------------------------------------
+def _bn_eval(u: Tensor, p: Dict[str, Tensor], prefix: str) -> Tensor:
+    """nn.BatchNorm1d in eval mode (latent_model.py:129,132,155,162-166)."""
+    return F.batch_norm(u, p[prefix + ".running_mean"], p[prefix + ".running_var"],
+                        p[prefix + ".weight"], p[prefix + ".bias"], False, 0.0, BN_EPS)
+
+
+def encoder_x(p: Dict[str, Tensor], x: Tensor) -> Tensor:
+    """``self.norm(self.encoder_x(x))`` -- latent_model.py:127-135,155,170-171.
+    t-invariant part of ConditionalModel.forward."""
+    h = F.linear(x, p["encoder_x.0.weight"], p["encoder_x.0.bias"])
+    h = F.softplus(_bn_eval(h, p, "encoder_x.1"))
+    h = F.linear(h, p["encoder_x.3.weight"], p["encoder_x.3.bias"])
+    h = F.softplus(_bn_eval(h, p, "encoder_x.4"))
+    h = F.linear(h, p["encoder_x.6.weight"], p["encoder_x.6.bias"])
+    return _bn_eval(h, p, "norm")
+
+
+def _cond_linear(p: Dict[str, Tensor], name: str, h: Tensor, t: Tensor) -> Tensor:
+    """ConditionalLinear.forward -- latent_model.py:101-105."""
+    out = F.linear(h, p[name + ".lin.weight"], p[name + ".lin.bias"])
+    gamma = F.embedding(t, p[name + ".embed.weight"])
+    return gamma.view(-1, out.shape[-1]) * out
+
+
+def trunk(p: Dict[str, Tensor], xe: Tensor, y: Tensor, t: Tensor, yhat: Optional[Tensor]) -> Tensor:
+    """t-dependent part of ConditionalModel.forward -- latent_model.py:172-184."""
+    if yhat is not None:                                   # guidance=True (:172-173)
+        y = torch.cat([y, yhat], dim=-1)
+    y = F.softplus(_bn_eval(_cond_linear(p, "lin1", y, t), p, "unetnorm1"))   # :174-176
+    y = xe * y                                                                 # :177
+    y = F.softplus(_bn_eval(_cond_linear(p, "lin2", y, t), p, "unetnorm2"))   # :178-180
+    y = F.softplus(_bn_eval(_cond_linear(p, "lin3", y, t), p, "unetnorm3"))   # :181-183
+    return F.linear(y, p["lin4.weight"], p["lin4.bias"])                      # :184
+
+
+def cond_model_forward(p: Dict[str, Tensor], x: Tensor, y: Tensor, t: Tensor,
+                       yhat: Optional[Tensor] = None) -> Tensor:
+    """ConditionalModel.forward as written (encoder re-evaluated) -- latent_model.py:169-184."""
+    return trunk(p, encoder_x(p, x), y, t, yhat)
+
+
+def init_cond_model_params(data_dim: int, hidden: int, feature: int, y_dim: int, n_steps: int,
+                           guidance: bool = True, seed: int = 0,
+                           randomize_bn: bool = True) -> Dict[str, Tensor]:
+    """Synthetic state_dict with the reference's key names/shapes (latent_model.py:108-167;
+    SURVEY 8c key list).  nn.Linear default init; embed ~ U(0,1) (latent_model.py:99);
+    BN running stats randomised so the eval-BN fold is exercised."""
+    g = torch.Generator().manual_seed(seed)
+    p: Dict[str, Tensor] = {}
+
+    def lin(name, n_in, n_out):
+        bound = 1.0 / math.sqrt(n_in)
+        p[name + ".weight"] = (torch.rand(n_out, n_in, generator=g) * 2 - 1) * bound
+        p[name + ".bias"] = (torch.rand(n_out, generator=g) * 2 - 1) * bound
+
+    def bn(name, n):
+        if randomize_bn:
+            p[name + ".weight"] = torch.rand(n, generator=g) + 0.5
+            p[name + ".bias"] = torch.randn(n, generator=g) * 0.5
+            p[name + ".running_mean"] = torch.randn(n, generator=g) * 0.5
+            p[name + ".running_var"] = torch.rand(n, generator=g) * 1.5 + 0.5
+        else:
+            p[name + ".weight"] = torch.ones(n)
+            p[name + ".bias"] = torch.zeros(n)
+            p[name + ".running_mean"] = torch.zeros(n)
+            p[name + ".running_var"] = torch.ones(n)
+        p[name + ".num_batches_tracked"] = torch.tensor(0, dtype=torch.long)
+
+    lin("encoder_x.0", data_dim, hidden); bn("encoder_x.1", hidden)
+    lin("encoder_x.3", hidden, hidden);   bn("encoder_x.4", hidden)
+    lin("encoder_x.6", hidden, feature);  bn("norm", feature)
+    lin("lin1.lin", y_dim * 2 if guidance else y_dim, feature)
+    p["lin1.embed.weight"] = torch.rand(n_steps + 1, feature, generator=g)
+    bn("unetnorm1", feature)
+    for name in ("lin2", "lin3"):
+        lin(name + ".lin", feature, feature)
+        p[name + ".embed.weight"] = torch.rand(n_steps + 1, feature, generator=g)
+        bn("unetnorm" + name[-1], feature)
+    lin("lin4", feature, y_dim)
+    return p
+
+
+# ----------------------------------------------------------------------------
+# sampler  (diffusion/diffusion_utils.py:31-35, 54-111, 133-163)
+# ----------------------------------------------------------------------------
+def extract(table: Tensor, t: Tensor, x: Tensor) -> Tensor:
+    """diffusion_utils.py:31-35."""
+    out = torch.gather(table, 0, t)
+    return out.reshape([t.shape[0]] + [1] * (x.dim() - 1))
+
+
+def p_sample_given_eps(y: Tensor, y_T_mean: Tensor, eps_theta: Tensor, t: int, alphas: Tensor,
+                       omabs: Tensor, z: Tensor) -> Tensor:
+    """Posterior update of p_sample with eps_theta and the noise draw supplied --
+    diffusion_utils.py:68-92, operation order preserved."""
+    tt = torch.tensor([t])
+    alpha_t = extract(alphas, tt, y)
+    s_t = extract(omabs, tt, y)
+    s_tm1 = extract(omabs, tt - 1, y)
+    sab_t = (1 - s_t.square()).sqrt()
+    sab_tm1 = (1 - s_tm1.square()).sqrt()
+    gamma_0 = (1 - alpha_t) * sab_tm1 / (s_t.square())
+    gamma_1 = (s_tm1.square()) * (alpha_t.sqrt()) / (s_t.square())
+    gamma_2 = 1 + (sab_t - 1) * (alpha_t.sqrt() + sab_tm1) / (s_t.square())
+    y_0_reparam = 1 / sab_t * (y - (1 - sab_t) * y_T_mean - eps_theta * s_t)
+    y_t_m_1_hat = gamma_0 * y_0_reparam + gamma_1 * y + gamma_2 * y_T_mean
+    beta_t_hat = (s_tm1.square()) / (s_t.square()) * (1 - alpha_t)
+    return y_t_m_1_hat + beta_t_hat.sqrt() * z
+
+
+def p_sample_t_1to0_given_eps(y: Tensor, y_T_mean: Tensor, eps_theta: Tensor, omabs: Tensor) -> Tensor:
+    """diffusion_utils.py:99-111 with eps_theta supplied."""
+    tt = torch.tensor([0])
+    s_t = extract(omabs, tt, y)
+    sab_t = (1 - s_t.square()).sqrt()
+    return 1 / sab_t * (y - (1 - sab_t) * y_T_mean - eps_theta * s_t)
+
+
+def p_sample_loop(p: Dict[str, Tensor], x: Tensor, y_0_hat: Tensor, y_T_mean: Tensor, n_steps: int,
+                  alphas: Tensor, omabs: Tensor, noise: Tensor, only_last_sample: bool = True,
+                  hoist: bool = True):
+    """p_sample_loop (diffusion_utils.py:133-163) with the RNG draws supplied as
+    ``noise[n_steps, B, C]`` in the reference's draw order: row 0 is the initial
+    ``randn_like(y_T_mean)`` (:139), row i (i>=1) is the draw inside p_sample for
+    t = n_steps - i (:67).  ``hoist=True`` evaluates the t-invariant encoder once
+    (bit-identical on CPU); ``hoist=False`` is the as-written cost model."""
+    assert noise.shape[0] == n_steps
+    xe = encoder_x(p, x) if hoist else None
+    cur_y = noise[0] + y_T_mean                                     # :139-140
+    seq = [cur_y]
+    for i, t in enumerate(reversed(range(1, n_steps)), start=1):    # :145
+        tt = torch.tensor([t])
+        xe_t = xe if hoist else encoder_x(p, x)
+        eps = trunk(p, xe_t, cur_y, tt, y_0_hat)                    # :81
+        cur_y = p_sample_given_eps(cur_y, y_T_mean, eps, t, alphas, omabs, noise[i])
+        seq.append(cur_y)
+    xe_t = xe if hoist else encoder_x(p, x)
+    eps = trunk(p, xe_t, cur_y, torch.tensor([0]), y_0_hat)         # :103
+    y_0 = p_sample_t_1to0_given_eps(cur_y, y_T_mean, eps, omabs)    # :155
+    if only_last_sample:
+        return y_0
+    seq.append(y_0)
+    return seq
+
+
+# ----------------------------------------------------------------------------
+# mapping network  (mapping/models/mlp.py:23-29; timm 0.4.12 ViT, call sites
+# classification_train_separately.py:337-346)
+# ----------------------------------------------------------------------------
+def classifier_forward(p: Dict[str, Tensor], x: Tensor) -> Tensor:
+    """mapping/models/mlp.py:23-29 (dropout declared, unused in forward).
+    The reference hard-codes reshape(-1, 196*768); small-dim tests use linear1's
+    in_features instead, identical at config dims."""
+    x = x.reshape(-1, p["linear1.weight"].shape[1])
+    x = F.relu(F.linear(x, p["linear1.weight"], p["linear1.bias"]))
+    x = F.relu(F.linear(x, p["linear2.weight"], p["linear2.bias"]))
+    x = F.relu(F.linear(x, p["linear3.weight"], p["linear3.bias"]))
+    return F.linear(x, p["linear4.weight"], p["linear4.bias"])
+
+
+def init_classifier_params(in_features: int, widths: Sequence[int] = (4096, 2048, 128),
+                           num_classes: int = 2, seed: int = 0) -> Dict[str, Tensor]:
+    g = torch.Generator().manual_seed(seed)
+    p: Dict[str, Tensor] = {}
+    dims = [in_features, *widths, num_classes]
+    for i in range(4):
+        bound = 1.0 / math.sqrt(dims[i])
+        p[f"linear{i + 1}.weight"] = (torch.rand(dims[i + 1], dims[i], generator=g) * 2 - 1) * bound
+        p[f"linear{i + 1}.bias"] = (torch.rand(dims[i + 1], generator=g) * 2 - 1) * bound
+    return p
+
+
+def vit_patch_embed(vp: Dict[str, Tensor], x: Tensor) -> Tensor:
+    """timm 0.4.12 PatchEmbed.forward: proj(x).flatten(2).transpose(1, 2); norm=Identity.
+    pos_drop is identity in eval.  NOTE no cls token and no pos_embed on the mapping path
+    (classification_train_separately.py:337-338)."""
+    w = vp["patch_embed.proj.weight"]
+    ps = w.shape[-1]
+    return F.conv2d(x, w, vp["patch_embed.proj.bias"], stride=ps).flatten(2).transpose(1, 2)
+
+
+def vit_block(vp: Dict[str, Tensor], i: int, x: Tensor, num_heads: int) -> Tensor:
+    """timm 0.4.12 Block.forward (pre-LN): x += attn(norm1(x)); x += mlp(norm2(x));
+    Attention: qkv -> [3,B,h,N,d]; softmax((q k^T) * d^-0.5) v; proj.  Mlp: fc1, exact GELU, fc2."""
+    pre = f"blocks.{i}."
+    B, N, C = x.shape
+    d = C // num_heads
+    h = F.layer_norm(x, (C,), vp[pre + "norm1.weight"], vp[pre + "norm1.bias"], LN_EPS)
+    qkv = F.linear(h, vp[pre + "attn.qkv.weight"], vp[pre + "attn.qkv.bias"])
+    qkv = qkv.reshape(B, N, 3, num_heads, d).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv[0], qkv[1], qkv[2]
+    attn = (q @ k.transpose(-2, -1)) * (d ** -0.5)
+    attn = attn.softmax(dim=-1)
+    h = (attn @ v).transpose(1, 2).reshape(B, N, C)
+    h = F.linear(h, vp[pre + "attn.proj.weight"], vp[pre + "attn.proj.bias"])
+    x = x + h
+    h = F.layer_norm(x, (C,), vp[pre + "norm2.weight"], vp[pre + "norm2.bias"], LN_EPS)
+    h = F.gelu(F.linear(h, vp[pre + "mlp.fc1.weight"], vp[pre + "mlp.fc1.bias"]))
+    h = F.linear(h, vp[pre + "mlp.fc2.weight"], vp[pre + "mlp.fc2.bias"])
+    return x + h
+
+
+def vit_full_forward(vp: Dict[str, Tensor], x: Tensor, num_heads: int, depth: int) -> Tensor:
+    """timm 0.4.12 VisionTransformer.forward (cls token + pos_embed, final norm, head on cls)."""
+    h = vit_patch_embed(vp, x)
+    cls = vp["cls_token"].expand(h.shape[0], -1, -1)
+    h = torch.cat((cls, h), dim=1) + vp["pos_embed"]
+    for i in range(depth):
+        h = vit_block(vp, i, h, num_heads)
+    C = h.shape[-1]
+    h = F.layer_norm(h, (C,), vp["norm.weight"], vp["norm.bias"], LN_EPS)
+    return F.linear(h[:, 0], vp["head.weight"], vp["head.bias"])
+
+
+def init_vit_params(embed: int = 768, depth: int = 12, mlp_ratio: int = 4, patch: int = 16,
+                    in_chans: int = 3, img: int = 224, num_classes: int = 2, seed: int = 0
+                    ) -> Dict[str, Tensor]:
+    """Synthetic timm-0.4.12-shaped ViT state_dict (random init; LN affine randomised)."""
+    g = torch.Generator().manual_seed(seed)
+    n_tok = (img // patch) ** 2
+    vp: Dict[str, Tensor] = {}
+
+    def lin(name, n_in, n_out, std=None):
+        s = std if std is not None else 1.0 / math.sqrt(n_in)
+        vp[name + ".weight"] = torch.randn(n_out, n_in, generator=g) * s
+        vp[name + ".bias"] = torch.randn(n_out, generator=g) * 0.02
+
+    def ln(name):
+        vp[name + ".weight"] = 1.0 + 0.1 * torch.randn(embed, generator=g)
+        vp[name + ".bias"] = 0.05 * torch.randn(embed, generator=g)
+
+    vp["cls_token"] = torch.randn(1, 1, embed, generator=g) * 0.02
+    vp["pos_embed"] = torch.randn(1, n_tok + 1, embed, generator=g) * 0.02
+    fan = in_chans * patch * patch
+    vp["patch_embed.proj.weight"] = torch.randn(embed, in_chans, patch, patch, generator=g) / math.sqrt(fan)
+    vp["patch_embed.proj.bias"] = torch.randn(embed, generator=g) * 0.02
+    for i in range(depth):
+        pre = f"blocks.{i}."
+        ln(pre + "norm1"); lin(pre + "attn.qkv", embed, 3 * embed); lin(pre + "attn.proj", embed, embed)
+        ln(pre + "norm2"); lin(pre + "mlp.fc1", embed, mlp_ratio * embed)
+        lin(pre + "mlp.fc2", mlp_ratio * embed, embed)
+    ln("norm")
+    lin("head", embed, num_classes)
+    return vp
+
+
+def compute_guiding_prediction(vp: Dict[str, Tensor], mlps: List[Dict[str, Tensor]], x: Tensor,
+                               num_heads: int, depth: int, full_vit: bool = True,
+                               share_prefix: bool = True) -> List[Tensor]:
+    """classification_train_separately.py:330-348: member i (1..K) = patch_embed -> blocks[0..i-1]
+    -> mlps[i-1]; last element = full vit(x).  share_prefix=True reuses block j's output across
+    members (identical values: eval mode, deterministic ops); False recomputes as written."""
+    out: List[Tensor] = []
+    if share_prefix:
+        tok = vit_patch_embed(vp, x)
+        for i in range(1, len(mlps) + 1):
+            tok = vit_block(vp, i - 1, tok, num_heads)
+            out.append(classifier_forward(mlps[i - 1], tok))
+    else:
+        for i in range(1, len(mlps) + 1):
+            tok = vit_patch_embed(vp, x)
+            for j in range(i):
+                tok = vit_block(vp, j, tok, num_heads)
+            out.append(classifier_forward(mlps[i - 1], tok))
+    if full_vit:
+        out.append(vit_full_forward(vp, x, num_heads, depth))
+    return out
+
+
+# ----------------------------------------------------------------------------
+# aggregation  (classification_train_separately.py:51-68, 392-398, 425-447)
+# ----------------------------------------------------------------------------
+def convert_to_prob(y: Tensor, temperature: float) -> Tensor:
+    """classification_train_separately.py:392-398."""
+    logits = ((y - 1.0) ** 2) * (-1.0) / temperature
+    return torch.softmax(logits, dim=-1)
+
+
+def compute_ensemble_confidence(samples: List[Tensor], temperature: float) -> Tensor:
+    """classification_train_separately.py:425-447 (mutates the caller's list, quirk Q4)."""
+    for i in range(len(samples)):
+        samples[i] = convert_to_prob(samples[i], temperature)
+    return torch.mean(torch.stack(samples), dim=0)
+
+
+def majority_voting_for_mc_samples(samples: List[Tensor]) -> Tensor:
+    """classification_train_separately.py:51-68: mode of per-sample argmax; ties -> smallest label
+    (torch.unique returns sorted labels, counts.argmax returns the first maximum)."""
+    votes = torch.stack([torch.argmax(s, dim=1) for s in samples]).transpose(0, 1)
+    out = []
+    for i in range(votes.shape[0]):
+        labels, counts = torch.unique(votes[i], return_counts=True)
+        out.append(labels[counts.argmax()])
+    return torch.stack(out)
+
+
+# ----------------------------------------------------------------------------
+# whole hot path  (classification_train_separately.py:749-794)
+# ----------------------------------------------------------------------------
+def ensemble_predict(members: List[Dict[str, Tensor]], x_flat: Tensor, yhat_list: List[Tensor],
+                     n_steps: int, alphas: Tensor, omabs: Tensor, noise: Tensor, temperature: float,
+                     hoist: bool = True):
+    """test_atk :767-789 with noise[K, mc, T, B, C] supplied.  Returns (samples list member-major
+    then trial, vote, prob)."""
+    K, mc = noise.shape[0], noise.shape[1]
+    samples: List[Tensor] = []
+    for k in range(K):
+        for j in range(mc):
+            samples.append(p_sample_loop(members[k], x_flat, yhat_list[k], yhat_list[k], n_steps,
+                                         alphas, omabs, noise[k, j], True, hoist))
+    vote = majority_voting_for_mc_samples(samples)            # :786 (raw y_0)
+    raw = [s.clone() for s in samples]
+    prob = compute_ensemble_confidence(samples, temperature)  # :789
+    return raw, vote, prob

@@ -1,0 +1,105 @@
+"""The oracle (oracle/ref_cpu.py) against fixtures produced by running the reference itself
+(tools/gen_golden.py).  CPU only.  Tolerances: bit-exact where the oracle performs the same
+torch ops in the same order (schedule, sampler, eps_theta, aggregation)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_cpu
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _load(name):
+    return np.load(os.path.join(G, name))
+
+
+def _params(z):
+    return {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("p.")}
+
+
+def test_schedule_tables_bit_exact():
+    z = _load("schedule.npz")
+    for T in (10, 100, 1000):
+        alphas, omabs = ref_cpu.schedule_tables("linear", T, 1e-4, 0.02)
+        assert np.array_equal(alphas.numpy(), z[f"alphas_{T}"])
+        assert np.array_equal(omabs.numpy(), z[f"omabs_{T}"])
+        assert np.array_equal(ref_cpu.make_beta_schedule("linear", T, 1e-4, 0.02).float().numpy(), z[f"betas_{T}"])
+    for sched in ("cosine", "cosine_anneal", "quad", "sigmoid", "const", "jsd"):
+        b = ref_cpu.make_beta_schedule(sched, 50, 1e-4, 0.02).float().numpy()
+        assert np.array_equal(b, z[f"betas_{sched}_50"]), sched
+
+
+@pytest.mark.parametrize("name", ["s0", "s1", "s2", "s3"])
+def test_sampler_small_bit_exact(name):
+    z = _load(f"sampler_{name}.npz")
+    p = _params(z)
+    D, H, Fd, C, T, B, seed = [int(v) for v in z["dims"]]
+    x, yhat, noise = (torch.from_numpy(z[k]) for k in ("x", "yhat", "noise"))
+    alphas, omabs = torch.from_numpy(z["alphas"]), torch.from_numpy(z["omabs"])
+    ref_seq = z["seq"]
+    for hoist in (True, False):
+        seq = ref_cpu.p_sample_loop(p, x, yhat, yhat, T, alphas, omabs, noise, only_last_sample=False, hoist=hoist)
+        got = torch.stack(seq).numpy()
+        assert got.shape == ref_seq.shape == (T + 1, B, C)
+        assert np.array_equal(got, ref_seq), (name, hoist, np.abs(got - ref_seq).max())
+    y0 = ref_cpu.p_sample_loop(p, x, yhat, yhat, T, alphas, omabs, noise, only_last_sample=True)
+    assert np.array_equal(y0.numpy(), ref_seq[-1])
+
+
+@pytest.mark.parametrize("name", ["s0", "s1", "s2", "s3"])
+def test_eps_theta_calls_bit_exact(name):
+    z = _load(f"sampler_{name}.npz")
+    p = _params(z)
+    D, H, Fd, C, T, B, seed = [int(v) for v in z["dims"]]
+    x, yhat = torch.from_numpy(z["x"]), torch.from_numpy(z["yhat"])
+    seq = torch.from_numpy(z["seq"])
+    for i, t in enumerate(z["eps_ts"]):
+        yy = seq[min(T - 1 - int(t), T - 1)]
+        e = ref_cpu.cond_model_forward(p, x, yy, torch.tensor([int(t)]), yhat)
+        assert np.array_equal(e.numpy(), z["eps"][i]), (name, t)
+    big = ref_cpu.cond_model_forward(p, x * 40.0, seq[0] * 30.0, torch.tensor([T - 1]), yhat)
+    assert np.array_equal(big.numpy(), z["eps_big"])
+
+
+def test_aggregation_bit_exact():
+    z = _load("aggregation.npz")
+    for name in ("a0", "a1", "a2"):
+        temp = float(z[name + "_temp"])
+        samples = [torch.from_numpy(s) for s in z[name + "_samples"]]
+        vote = ref_cpu.majority_voting_for_mc_samples([s.clone() for s in samples])
+        assert np.array_equal(vote.numpy(), z[name + "_vote"])
+        assert np.array_equal(ref_cpu.convert_to_prob(samples[0], temp).numpy(), z[name + "_p1"])
+        lst = [s.clone() for s in samples]
+        prob = ref_cpu.compute_ensemble_confidence(lst, temp)
+        assert np.array_equal(prob.numpy(), z[name + "_prob"])
+        assert np.array_equal(torch.stack(lst).numpy(), z[name + "_mutated"])      # quirk Q4
+    # the documented raw-argmax vs closest-to-one disagreement (SURVEY a-16)
+    s = [torch.from_numpy(x) for x in z["a1_samples"]]
+    assert int(z["a1_vote"][0]) == 0          # tie 2:2 -> smallest label
+
+
+@pytest.mark.slow
+def test_classifier_full_dims():
+    z = _load("classifier_full.npz")
+    B, seed, xseed = [int(v) for v in z["dims"]]
+    p = ref_cpu.init_classifier_params(196 * 768, seed=seed)
+    tok = torch.randn(B, 196, 768, generator=torch.Generator().manual_seed(xseed))
+    out = ref_cpu.classifier_forward(p, tok)
+    assert np.array_equal(out.numpy(), z["out"])
+
+
+@pytest.mark.slow
+def test_sampler_full_dims():
+    z = _load("sampler_full.npz")
+    D, H, Fd, C, T, B, seed = [int(v) for v in z["dims"]]
+    p = ref_cpu.init_cond_model_params(D, H, Fd, C, T, True, seed=seed)
+    x = torch.rand(B, D, generator=torch.Generator().manual_seed(int(z["x_seed"])))
+    yhat, noise = torch.from_numpy(z["yhat"]), torch.from_numpy(z["noise"])
+    alphas, omabs = ref_cpu.schedule_tables("linear", T, 1e-4, 0.02)
+    xe = ref_cpu.encoder_x(p, x)
+    assert np.array_equal(xe.numpy(), z["xe"])
+    seq = ref_cpu.p_sample_loop(p, x, yhat, yhat, T, alphas, omabs, noise, only_last_sample=False, hoist=True)
+    assert np.array_equal(torch.stack(seq).numpy(), z["seq"])
