@@ -1,0 +1,169 @@
+/*
+ * nested_diffusion.h -- C ABI of libnd_hip.so, the MI355X (gfx950) implementation of the
+ * nested-diffusion (LaDiNE) inference hot path.
+ *
+ * The reference (xingbpshen/nested-diffusion) has no FFI: its hot path is plain Python calling
+ * torch ops.  Each entry point below therefore names the reference Python call(s) it replaces
+ * (file:line relative to the reference checkout).  The host side that mirrors the reference's
+ * Python API lives in nested_diffusion_amd/ and binds this library with ctypes.
+ *
+ * Conventions
+ *  - plain C types only; every `*_dev` pointer is a DEVICE pointer owned by the caller
+ *    (PyTorch-ROCm tensors in practice); the library never allocates device memory --
+ *    the caller provides one workspace of nd_workspace_bytes().
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream).
+ *  - every function returns 0 on success, <0 on error; nd_last_error() gives the message.
+ *    No C++ exception crosses the ABI.
+ *  - fp32 storage and arithmetic throughout (f32-input MFMA, exact f32 products/accumulate).
+ *  - one handle per GPU per process; not thread-safe for concurrent calls on one handle.
+ */
+#ifndef NESTED_DIFFUSION_H
+#define NESTED_DIFFUSION_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ND_OK 0
+#define ND_ERR_ARG (-1)
+#define ND_ERR_HIP (-2)
+#define ND_ERR_STATE (-3)
+
+/* activation codes for the generic linear entry points */
+#define ND_ACT_NONE 0
+#define ND_ACT_SOFTPLUS 1 /* torch softplus beta=1 threshold=20 (latent_model.py:130,133,176,180,183) */
+#define ND_ACT_RELU 2     /* mapping/models/mlp.py:25-27 */
+#define ND_ACT_GELU 3     /* exact erf GELU, timm 0.4.12 Mlp */
+
+typedef struct nd_handle_s *nd_handle;
+
+/* Dimensions of one ensemble: K ConditionalModel members (latent_model.py:108-167, arch 'linear',
+ * guidance=True) that share shapes.  Config dims: y_dim 2, data_dim 150528, hidden 4096,
+ * feature 4096 (configs/chest_x_ray.yml:5,11,14-15). */
+typedef struct {
+    int32_t y_dim;       /* C  = config.data.num_classes */
+    int32_t data_dim;    /* D  = config.model.data_dim          (multiple of 16) */
+    int32_t hidden_dim;  /* H  = config.model.hidden_dim        (multiple of 16) */
+    int32_t feature_dim; /* F  = config.model.feature_dim       (multiple of 16) */
+    int32_t n_steps;     /* T  = config.diffusion.timesteps; embed tables hold T+1 rows */
+    int32_t n_members;   /* K  */
+    int32_t max_batch;   /* largest B (images) per call */
+    int32_t max_rows;    /* largest M = B * mc_trials per call */
+} nd_config;
+
+/* Device pointers to ONE member's raw parameters, exactly the tensors of
+ * ConditionalModel.state_dict() (key in the comment; shapes for config dims). */
+typedef struct {
+    const float *enc0_w, *enc0_b;                       /* encoder_x.0.{weight [H,D], bias [H]} */
+    const float *bn0_w, *bn0_b, *bn0_mean, *bn0_var;    /* encoder_x.1.* [H] */
+    const float *enc3_w, *enc3_b;                       /* encoder_x.3.{weight [H,H], bias} */
+    const float *bn1_w, *bn1_b, *bn1_mean, *bn1_var;    /* encoder_x.4.* [H] */
+    const float *enc6_w, *enc6_b;                       /* encoder_x.6.{weight [F,H], bias} */
+    const float *norm_w, *norm_b, *norm_mean, *norm_var;/* norm.* [F] */
+    const float *lin1_w, *lin1_b, *emb1;                /* lin1.lin.{weight [F,2C], bias}, lin1.embed.weight [T+1,F] */
+    const float *un1_w, *un1_b, *un1_mean, *un1_var;    /* unetnorm1.* */
+    const float *lin2_w, *lin2_b, *emb2;                /* lin2.lin.{weight [F,F], bias}, lin2.embed.weight */
+    const float *un2_w, *un2_b, *un2_mean, *un2_var;    /* unetnorm2.* */
+    const float *lin3_w, *lin3_b, *emb3;                /* lin3.* */
+    const float *un3_w, *un3_b, *un3_mean, *un3_var;    /* unetnorm3.* */
+    const float *lin4_w, *lin4_b;                       /* lin4.{weight [C,F], bias [C]} */
+} nd_member_weights;
+
+const char *nd_last_error(void);
+/* "gfx950 f32 <build id>" -- lets the host assert the native library is the one loaded. */
+const char *nd_version(void);
+
+/* ---- ensemble handle --------------------------------------------------------------------- */
+int nd_create(const nd_config *cfg, nd_handle *out);
+int nd_destroy(nd_handle h);
+/* Bytes of device workspace the handle needs (folded tables, activations, split-K slabs). */
+size_t nd_workspace_bytes(const nd_config *cfg);
+int nd_bind_workspace(nd_handle h, void *workspace_dev, size_t bytes);
+
+/* Replaces ConditionalModel(...).load_state_dict(state['noise_estimator']) + .eval() + .to(device)
+ * (classification_train_separately.py:685-697, 773).  Keeps the raw weight pointers (the caller
+ * must keep them alive) and folds eval-mode BatchNorm1d, the Linear bias and the per-timestep
+ * Embedding gain into scale/shift tables:  BN(g_t * (W h + b)) = a_t * (W h) + c_t. */
+int nd_load_member(nd_handle h, int member, const nd_member_weights *w, void *stream);
+
+/* alphas / one_minus_alphas_bar_sqrt, as handed to p_sample_loop (diffusion_utils.py:133;
+ * built at classification_train_separately.py:215-226).  Device arrays of length T, copied. */
+int nd_set_schedule(nd_handle h, const float *alphas_dev, const float *omabs_dev, int T, void *stream);
+
+/* xe = norm(encoder_x(x)) for members [member0, member0+n_members)  -- latent_model.py:170-171.
+ * t-invariant, so evaluated ONCE per (member, batch) instead of once per denoising step.
+ * x_dev [B, D] row-major (images_224_flat, classification_train_separately.py:747). */
+int nd_encode(nd_handle h, int member0, int n_members, const float *x_dev, int B, void *stream);
+
+/* One eps_theta evaluation of the t-dependent trunk on the cached xe:
+ * ConditionalModel.forward lines latent_model.py:172-184.  y_dev [M,C], yhat_dev [B,C],
+ * eps_out_dev [M,C]; row m uses image m % B.  Used for unit parity tests and the nn.Module mirror. */
+int nd_eps_theta(nd_handle h, int member, const float *y_dev, const float *yhat_dev, int t,
+                 float *eps_out_dev, int B, int mc, void *stream);
+
+/* p_sample_loop(..., only_last_sample=True) for members [member0, member0+n_members) and mc
+ * Monte-Carlo trials at once (diffusion_utils.py:133-163 driven by the member x trial loop at
+ * classification_train_separately.py:767-777).  M = B*mc rows per member, row m = trial*B + image.
+ *   yhat_dev  [n_members, B, C]   eps_theta condition (y_0_hat)
+ *   ymean_dev [n_members, B, C]   prior mean y_T_mean (same tensor in the reference, quirk Q2)
+ *   noise_dev [n_members, T, M, C] the reference's RNG draws in draw order: index 0 = initial
+ *              randn_like (:139), index i>=1 = the draw of p_sample at t = T-i (:67)
+ *   y0_out_dev [n_members, M, C]
+ *   seq_out_dev optional [n_members, T+1, M, C]: y_T, y_{T-1}, ..., y_0 (only_last_sample=False)
+ * The 3T+1 kernels are replayed from one hipGraph per (member range, B, mc, T, pointers) when
+ * use_graph != 0.  nd_encode must have run for these members with the same B. */
+int nd_sample(nd_handle h, int member0, int n_members, const float *yhat_dev, const float *ymean_dev,
+              const float *noise_dev, float *y0_out_dev, float *seq_out_dev, int B, int mc, int T,
+              int use_graph, void *stream);
+
+/* Device address of an internal per-member buffer (tests/profiling): which = 0 xe [B,F],
+ * 1 h1 [M,F], 2 h2 [M,F]. */
+int nd_member_buffer(nd_handle h, int member, int which, void **out_dev);
+/* hipMemcpyAsync(device -> device) on `stream`; lets a host without HIP bindings read such a buffer. */
+int nd_memcpy_d2d(void *dst_dev, const void *src_dev, size_t bytes, void *stream);
+
+/* ---- standalone operators (mapping network + unit tests) ---------------------------------- */
+/* out[M,N] = act(scale[n] * (x[M,K] . W[N,K]^T) + shift[n]); scale/shift may be NULL (1 / 0).
+ * nn.Linear + bias (+ReLU) of mapping/models/mlp.py:25-28 with shift = bias; skinny-M weight
+ * streaming, split-K across workgroups when K is large.  workspace_dev: >= nd_linear_workspace_bytes. */
+size_t nd_linear_workspace_bytes(int M, int K, int N);
+int nd_linear(const float *x_dev, const float *w_dev, const float *scale_dev, const float *shift_dev,
+              float *out_dev, int M, int K, int N, int act, void *workspace_dev, size_t workspace_bytes,
+              void *stream);
+
+/* Large-M GEMM for the ViT blocks: out[M,N] = act(x[M,K] . W[N,K]^T + bias[n]) (+ residual[M,N]).
+ * timm 0.4.12 Attention.qkv / proj, Mlp.fc1 (GELU) / fc2, PatchEmbed.proj as GEMM
+ * (call sites classification_train_separately.py:337-340). */
+int nd_gemm_bias_act(const float *x_dev, const float *w_dev, const float *bias_dev, const float *residual_dev,
+                     float *out_dev, int M, int K, int N, int act, void *stream);
+
+/* nn.LayerNorm(eps) over the last dim: x [rows, dim] -> out.  timm Block.norm1/norm2 (eps 1e-6). */
+int nd_layernorm(const float *x_dev, const float *gamma_dev, const float *beta_dev, float *out_dev,
+                 int rows, int dim, float eps, void *stream);
+
+/* timm 0.4.12 Attention core: qkv [B, N, 3, heads, d] (the qkv Linear's output, unpermuted) ->
+ * out [B, N, heads*d] = softmax(q k^T * d^-0.5) v, heads concatenated.  d must be 64. */
+int nd_attention(const float *qkv_dev, float *out_dev, int B, int N, int heads, int d, void *stream);
+
+/* PatchEmbed im2col: img [B, Cin, Himg, Wimg] NCHW -> cols [B * (Himg/p) * (Wimg/p), Cin*p*p] so that
+ * Conv2d(k=p, s=p) becomes nd_gemm_bias_act with the conv weight viewed [embed, Cin*p*p]. */
+int nd_patchify(const float *img_dev, float *cols_dev, int B, int Cin, int Himg, int Wimg, int p, void *stream);
+
+/* softmax over the last dim of [rows, C] (classification_train_separately.py:755-758). */
+int nd_softmax_rows(const float *x_dev, float *out_dev, int rows, int C, void *stream);
+
+/* Aggregation: samples [S, B, C] (S = K*mc, member-major then trial) ->
+ *   prob_out [B, C]  = mean_s softmax(-(y-1)^2 / temperature)   (convert_to_prob + compute_ensemble_confidence,
+ *                      classification_train_separately.py:392-398, 425-447)
+ *   vote_out [B] int64 = mode_s argmax_c y  (ties -> smallest label; majority_voting_for_mc_samples :51-68)
+ *   probs_out optional [S, B, C]: per-sample probabilities (what the reference leaves in mc_samples, quirk Q4) */
+int nd_aggregate(const float *samples_dev, float *prob_out_dev, int64_t *vote_out_dev, float *probs_out_dev,
+                 int S, int B, int C, float temperature, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NESTED_DIFFUSION_H */

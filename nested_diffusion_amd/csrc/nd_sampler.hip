@@ -1,0 +1,635 @@
+// nd_sampler.hip -- ensemble handle, BN/gain folding, the per-step kernels of the DDPM reverse loop
+// and the hipGraph that replays a whole p_sample_loop.  gfx950 only.
+//
+// Reference path (file:line relative to the reference checkout):
+//   diffusion/diffusion_utils.py:133-163   p_sample_loop
+//   diffusion/diffusion_utils.py:54-111    p_sample / p_sample_t_1to0
+//   diffusion/latent_model.py:93-105,169-184  ConditionalLinear / ConditionalModel.forward
+#include "nd_common.hpp"
+#include "../../include/nested_diffusion.h"
+
+#include <map>
+#include <string>
+#include <tuple>
+#include <vector>
+#include <cstdio>
+#include <cstdarg>
+#include <cstring>
+
+// ---------------------------------------------------------------------------------------------
+// error plumbing
+// ---------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+extern "C" const char* nd_last_error(void) { return g_err.c_str(); }
+extern "C" const char* nd_version(void) { return "libnd_hip gfx950 f32-mfma r1"; }
+int nd_set_err(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIP_CHECK(expr)                                                                              \
+    do {                                                                                             \
+        hipError_t _e = (expr);                                                                      \
+        if (_e != hipSuccess)                                                                        \
+            return nd_set_err(ND_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// device-side member record (everything the head / final kernels need)
+// ---------------------------------------------------------------------------------------------
+struct MemberDev {
+    const float* lin1_w;   // [F, 2C]
+    const float* lin4_b;   // [C]
+    const float* A1;       // [T, F] folded gain  (unetnorm1 scale * embed1[t])
+    const float* C1;       // [T, F] folded shift
+    const float* xe;       // [B, F]
+    float* h1;             // [M, F]
+    float* ybuf;           // [2, maxM, C]
+    const float* epart;    // [NT, M, C]
+};
+
+struct StepIO {             // per-launch tensors with a member-major leading stride
+    const float* yhat;  size_t yhat_ms;    // [nm][B][C]
+    const float* ymean; size_t ymean_ms;   // [nm][B][C]
+    const float* noise; size_t noise_ms;   // [nm][T][M][C]
+    float* y0_out;      size_t y0_ms;      // [nm][M][C]
+    float* seq_out;     size_t seq_ms;     // [nm][T+1][M][C] or null
+    const float* y_in;  size_t yin_ms;     // [nm][M][C] (eps_theta entry point only)
+    const float* alphas; const float* omabs;
+};
+
+// diffusion_utils.py:68-92 in the reference's operation order, fp32, no FMA contraction, so the
+// posterior is bit-identical to the CPU path for identical eps.
+__device__ __forceinline__ float nd_posterior(float y, float ymean, float eps, float z, float alpha_t, float s_t,
+                                              float s_tm1) {
+#pragma clang fp contract(off)
+    const float st2 = s_t * s_t;
+    const float sab_t = sqrtf(1.0f - st2);
+    const float stm2 = s_tm1 * s_tm1;
+    const float sab_tm1 = sqrtf(1.0f - stm2);
+    const float sa = sqrtf(alpha_t);
+    const float g0 = (1.0f - alpha_t) * sab_tm1 / st2;
+    const float g1 = stm2 * sa / st2;
+    const float g2 = 1.0f + (sab_t - 1.0f) * (sa + sab_tm1) / st2;
+    const float y0r = 1.0f / sab_t * (y - (1.0f - sab_t) * ymean - eps * s_t);
+    const float mean = g0 * y0r + g1 * y + g2 * ymean;
+    const float bh = stm2 / st2 * (1.0f - alpha_t);
+    return mean + sqrtf(bh) * z;
+}
+
+// diffusion_utils.py:99-111
+__device__ __forceinline__ float nd_y0_reparam(float y, float ymean, float eps, float s_t) {
+#pragma clang fp contract(off)
+    const float sab_t = sqrtf(1.0f - s_t * s_t);
+    return 1.0f / sab_t * (y - (1.0f - sab_t) * ymean - eps * s_t);
+}
+
+// eps[m, c] = lin4.bias[c] + sum over the n-tiles of lin3's projected partials; fixed reduction
+// tree (thread-strided, wave shuffle, then waves in order) => reproducible.
+template <int NT_THREADS>
+__device__ __forceinline__ float nd_reduce_eps(const float* __restrict__ epart, int NT, int M, int m, int C, int c,
+                                               float* red /* [NT_THREADS/64] */) {
+    const int tid = threadIdx.x;
+    float s = 0.f;
+    for (int tl = tid; tl < NT; tl += NT_THREADS) s += epart[((size_t)tl * M + m) * C + c];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < NT_THREADS / 64; ++w) tot += red[w];
+    return tot;
+}
+
+#define ND_HEAD_INIT 0    // y = noise[0] + y_T_mean                       (diffusion_utils.py:139-140)
+#define ND_HEAD_UPDATE 1  // y = posterior(y, eps(t_prev), noise[i])       (diffusion_utils.py:66-92)
+#define ND_HEAD_GIVEN 2   // y = y_in (single eps_theta evaluation)
+#define ND_MAX_C 8
+
+// Step head: finish the previous step (reduce eps, posterior update -> y_t), then the first
+// ConditionalLinear block of this step:  h1 = softplus(A1[t] * (lin1.W [y_t, yhat]) + C1[t]) * xe
+// (latent_model.py:173-177).  Grid (ceil(F/1024), M, members), 256 threads, 4 columns per thread.
+__global__ __launch_bounds__(256) void k_step_head(const MemberDev* __restrict__ members, StepIO io, int mode, int i_step,
+                                                   int t_prev, int t, int B, int M, int maxM, int C, int F, int NT, int T) {
+    const MemberDev mb = members[blockIdx.z];
+    const int z = blockIdx.z, m = blockIdx.y, b = m % B, tid = threadIdx.x;
+    __shared__ float red[4];
+    __shared__ float ysh[2 * ND_MAX_C];
+    const float* yhat = io.yhat + z * io.yhat_ms + (size_t)b * C;
+    const int par_new = i_step & 1;                       // ybuf parity written by this step
+    float* ynew = mb.ybuf + ((size_t)par_new * maxM + m) * C;
+    const float* yold = mb.ybuf + ((size_t)(par_new ^ 1) * maxM + m) * C;
+
+    for (int c = 0; c < C; ++c) {
+        float yv;
+        if (mode == ND_HEAD_INIT) {
+            const float ymean = io.ymean[z * io.ymean_ms + (size_t)b * C + c];
+            yv = io.noise[z * io.noise_ms + ((size_t)0 * M + m) * C + c] + ymean;
+        } else if (mode == ND_HEAD_UPDATE) {
+            const float eps = nd_reduce_eps<256>(mb.epart, NT, M, m, C, c, red) + mb.lin4_b[c];
+            const float ymean = io.ymean[z * io.ymean_ms + (size_t)b * C + c];
+            const float zz = io.noise[z * io.noise_ms + ((size_t)i_step * M + m) * C + c];
+            yv = nd_posterior(yold[c], ymean, eps, zz, io.alphas[t_prev], io.omabs[t_prev], io.omabs[t_prev - 1]);
+        } else {
+            yv = io.y_in[z * io.yin_ms + (size_t)m * C + c];
+        }
+        if (tid == 0) {
+            ysh[c] = yv;
+            ysh[C + c] = yhat[c];
+            if (blockIdx.x == 0) {
+                ynew[c] = yv;
+                if (io.seq_out && mode != ND_HEAD_GIVEN) io.seq_out[z * io.seq_ms + ((size_t)i_step * M + m) * C + c] = yv;
+            }
+        }
+    }
+    __syncthreads();
+    const int n = blockIdx.x * 1024 + tid * 4;
+    if (n >= F) return;
+    const int C2 = 2 * C;
+    float u[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q < C2; ++q) {
+        const float yq = ysh[q];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) u[j] += mb.lin1_w[(size_t)(n + j) * C2 + q] * yq;
+    }
+    const float4 a = *reinterpret_cast<const float4*>(mb.A1 + (size_t)t * F + n);
+    const float4 cc = *reinterpret_cast<const float4*>(mb.C1 + (size_t)t * F + n);
+    const float4 xe = *reinterpret_cast<const float4*>(mb.xe + (size_t)b * F + n);
+    float4 h;
+    h.x = nd_softplus(a.x * u[0] + cc.x) * xe.x;
+    h.y = nd_softplus(a.y * u[1] + cc.y) * xe.y;
+    h.z = nd_softplus(a.z * u[2] + cc.z) * xe.z;
+    h.w = nd_softplus(a.w * u[3] + cc.w) * xe.w;
+    *reinterpret_cast<float4*>(mb.h1 + (size_t)m * F + n) = h;
+}
+
+// Last step (t = 0): y_0 = y_0_reparam (diffusion_utils.py:96-111), or plain eps output for the
+// eps_theta entry point.  Grid (M, 1, members), 64 threads.
+__global__ __launch_bounds__(64) void k_step_final(const MemberDev* __restrict__ members, StepIO io, int eps_only, int par_cur,
+                                                   int B, int M, int maxM, int C, int NT, int T, float* eps_out, size_t eps_ms) {
+    const MemberDev mb = members[blockIdx.z];
+    const int z = blockIdx.z, m = blockIdx.x, b = m % B;
+    __shared__ float red[1];
+    for (int c = 0; c < C; ++c) {
+        const float eps = nd_reduce_eps<64>(mb.epart, NT, M, m, C, c, red) + mb.lin4_b[c];
+        if (threadIdx.x == 0) {
+            if (eps_only) {
+                eps_out[z * eps_ms + (size_t)m * C + c] = eps;
+            } else {
+                const float y = mb.ybuf[((size_t)par_cur * maxM + m) * C + c];
+                const float ymean = io.ymean[z * io.ymean_ms + (size_t)b * C + c];
+                const float y0 = nd_y0_reparam(y, ymean, eps, io.omabs[0]);
+                io.y0_out[z * io.y0_ms + (size_t)m * C + c] = y0;
+                if (io.seq_out) io.seq_out[z * io.seq_ms + ((size_t)T * M + m) * C + c] = y0;
+            }
+        }
+    }
+}
+
+// ---- one-time folds, computed in fp64 and rounded once --------------------------
+// eval BatchNorm1d: BN(u) = s*u + o, s = w / sqrt(var + 1e-5), o = beta - mean*s
+// Linear bias folded: BN(W h + b) = s*(W h) + (s*b + o)
+__global__ void k_fold_bn(float* scale, float* shift, const float* lin_b, const float* bn_w, const float* bn_b,
+                          const float* bn_mean, const float* bn_var, int N) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const double s = (double)bn_w[n] / sqrt((double)bn_var[n] + 1e-5);
+    const double o = (double)bn_b[n] - (double)bn_mean[n] * s;
+    scale[n] = (float)s;
+    shift[n] = (float)(s * (double)lin_b[n] + o);
+}
+// ConditionalLinear + BN: BN(g_t * (W h + b)) = (s g_t) * (W h) + (s g_t b + o)
+__global__ void k_fold_steps(float* A, float* Cc, const float* emb, const float* lin_b, const float* bn_w, const float* bn_b,
+                             const float* bn_mean, const float* bn_var, int T, int N) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)T * N) return;
+    const int n = (int)(i % N);
+    const double s = (double)bn_w[n] / sqrt((double)bn_var[n] + 1e-5);
+    const double o = (double)bn_b[n] - (double)bn_mean[n] * s;
+    const double g = (double)emb[i];
+    A[i] = (float)(s * g);
+    Cc[i] = (float)(s * g * (double)lin_b[n] + o);
+}
+
+// ---------------------------------------------------------------------------------------------
+// host handle
+// ---------------------------------------------------------------------------------------------
+enum { L_ENC1 = 0, L_ENC2 = 1, L_LIN2 = 2, L_LIN3 = 3, L_COUNT = 4 };
+
+struct MemberHost {
+    bool loaded = false;
+    nd_member_weights w{};
+    float *sc0, *sh0, *sc1, *sh1, *sc2, *sh2;
+    float *A[3], *Cc[3];
+    float *e0, *e1, *xe, *ybuf, *h1, *h2, *epart, *splitk;
+};
+
+struct GraphKey {
+    int m0, nm, B, mc, T;
+    const void *yhat, *ymean, *noise, *y0, *seq;
+    bool operator<(const GraphKey& o) const {
+        return std::tie(m0, nm, B, mc, T, yhat, ymean, noise, y0, seq) <
+               std::tie(o.m0, o.nm, o.B, o.mc, o.T, o.yhat, o.ymean, o.noise, o.y0, o.seq);
+    }
+};
+
+struct nd_handle_s {
+    nd_config cfg{};
+    char* ws = nullptr;
+    size_t ws_bytes = 0;
+    std::vector<MemberHost> members;
+    MemberDev* members_dev = nullptr;      // [K]
+    SkinnyDesc* descs_dev = nullptr;       // [L_COUNT][K]
+    SplitKDesc* spk_dev = nullptr;         // [K]   encoder_x.0
+    SplitKEpiDesc* spke_dev = nullptr;     // [K]
+    float *alphas = nullptr, *omabs = nullptr;
+    int sched_T = 0;
+    int NT = 0, S0 = 0;
+    bool enc_splitk = false;
+    std::map<GraphKey, hipGraphExec_t> graphs;
+    int encoded_B = -1;
+};
+
+static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct Carver {
+    char* base; size_t off = 0;
+    template <typename T> T* take(size_t count) {
+        T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+        off = al256(off + count * sizeof(T));
+        return p;
+    }
+};
+
+static void carve(nd_handle_s* h, char* base, size_t* total) {
+    const nd_config& c = h->cfg;
+    const size_t K = c.n_members, H = c.hidden_dim, F = c.feature_dim, T = c.n_steps, C = c.y_dim;
+    const size_t mB = c.max_batch, mM = c.max_rows;
+    h->NT = (int)((F + 15) / 16);
+    h->enc_splitk = nd_use_splitk(c.data_dim);
+    h->S0 = h->enc_splitk ? nd_pick_splitk(c.data_dim, c.hidden_dim) : 0;
+    Carver cv{base};
+    h->members_dev = cv.take<MemberDev>(K);
+    h->descs_dev = cv.take<SkinnyDesc>(L_COUNT * K);
+    h->spk_dev = cv.take<SplitKDesc>(K);
+    h->spke_dev = cv.take<SplitKEpiDesc>(K);
+    h->alphas = cv.take<float>(T);
+    h->omabs = cv.take<float>(T);
+    for (size_t k = 0; k < K; ++k) {
+        MemberHost& m = h->members[k];
+        m.sc0 = cv.take<float>(H); m.sh0 = cv.take<float>(H);
+        m.sc1 = cv.take<float>(H); m.sh1 = cv.take<float>(H);
+        m.sc2 = cv.take<float>(F); m.sh2 = cv.take<float>(F);
+        for (int l = 0; l < 3; ++l) { m.A[l] = cv.take<float>(T * F); m.Cc[l] = cv.take<float>(T * F); }
+        m.e0 = cv.take<float>(mB * H); m.e1 = cv.take<float>(mB * H); m.xe = cv.take<float>(mB * F);
+        m.ybuf = cv.take<float>(2 * mM * C);
+        m.h1 = cv.take<float>(mM * F); m.h2 = cv.take<float>(mM * F);
+        m.epart = cv.take<float>((size_t)h->NT * mM * C);
+        m.splitk = cv.take<float>(h->enc_splitk ? (size_t)h->S0 * mB * H : 1);
+    }
+    *total = cv.off;
+}
+
+static int check_cfg(const nd_config* c) {
+    if (!c) return nd_set_err(ND_ERR_ARG, "cfg is NULL");
+    if (c->y_dim < 1 || c->y_dim > ND_MAX_C) return nd_set_err(ND_ERR_ARG, "y_dim must be in [1,%d]", ND_MAX_C);
+    if (c->data_dim < 16 || c->data_dim % 16) return nd_set_err(ND_ERR_ARG, "data_dim must be a positive multiple of 16");
+    if (c->hidden_dim < 16 || c->hidden_dim % 16) return nd_set_err(ND_ERR_ARG, "hidden_dim must be a positive multiple of 16");
+    if (c->feature_dim < 16 || c->feature_dim % 16) return nd_set_err(ND_ERR_ARG, "feature_dim must be a positive multiple of 16");
+    if (c->n_steps < 1) return nd_set_err(ND_ERR_ARG, "n_steps must be >= 1");
+    if (c->n_members < 1 || c->max_batch < 1 || c->max_rows < c->max_batch)
+        return nd_set_err(ND_ERR_ARG, "n_members/max_batch/max_rows invalid");
+    return ND_OK;
+}
+
+extern "C" size_t nd_workspace_bytes(const nd_config* cfg) {
+    if (check_cfg(cfg) != ND_OK) return 0;
+    nd_handle_s tmp;
+    tmp.cfg = *cfg;
+    tmp.members.resize(cfg->n_members);
+    size_t total = 0;
+    carve(&tmp, nullptr, &total);
+    return total;
+}
+
+extern "C" int nd_create(const nd_config* cfg, nd_handle* out) {
+    if (!out) return nd_set_err(ND_ERR_ARG, "out is NULL");
+    int rc = check_cfg(cfg);
+    if (rc != ND_OK) return rc;
+    nd_handle_s* h = new nd_handle_s();
+    h->cfg = *cfg;
+    h->members.resize(cfg->n_members);
+    *out = h;
+    return ND_OK;
+}
+
+static void drop_graphs(nd_handle_s* h) {
+    for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
+    h->graphs.clear();
+}
+
+extern "C" int nd_destroy(nd_handle h) {
+    if (!h) return ND_OK;
+    drop_graphs(h);
+    delete h;
+    return ND_OK;
+}
+
+extern "C" int nd_bind_workspace(nd_handle h, void* ws, size_t bytes) {
+    if (!h || !ws) return nd_set_err(ND_ERR_ARG, "handle/workspace is NULL");
+    if ((uintptr_t)ws & 255) return nd_set_err(ND_ERR_ARG, "workspace must be 256-byte aligned");
+    size_t need = 0;
+    carve(h, (char*)ws, &need);
+    if (bytes < need) return nd_set_err(ND_ERR_ARG, "workspace too small: %zu < %zu", bytes, need);
+    h->ws = (char*)ws;
+    h->ws_bytes = bytes;
+    drop_graphs(h);
+    return ND_OK;
+}
+
+extern "C" int nd_set_schedule(nd_handle h, const float* alphas_dev, const float* omabs_dev, int T, void* stream) {
+    if (!h || !h->ws) return nd_set_err(ND_ERR_STATE, "workspace not bound");
+    if (T < 1 || T > h->cfg.n_steps) return nd_set_err(ND_ERR_ARG, "T=%d outside [1,%d]", T, h->cfg.n_steps);
+    hipStream_t st = (hipStream_t)stream;
+    HIP_CHECK(hipMemcpyAsync(h->alphas, alphas_dev, sizeof(float) * T, hipMemcpyDeviceToDevice, st));
+    HIP_CHECK(hipMemcpyAsync(h->omabs, omabs_dev, sizeof(float) * T, hipMemcpyDeviceToDevice, st));
+    h->sched_T = T;
+    return ND_OK;
+}
+
+extern "C" int nd_load_member(nd_handle h, int k, const nd_member_weights* w, void* stream) {
+    if (!h || !h->ws) return nd_set_err(ND_ERR_STATE, "workspace not bound");
+    if (k < 0 || k >= h->cfg.n_members) return nd_set_err(ND_ERR_ARG, "member %d out of range", k);
+    if (!w) return nd_set_err(ND_ERR_ARG, "weights is NULL");
+    const void* const* pp = reinterpret_cast<const void* const*>(w);
+    for (size_t i = 0; i < sizeof(nd_member_weights) / sizeof(void*); ++i)
+        if (!pp[i]) return nd_set_err(ND_ERR_ARG, "nd_member_weights pointer #%zu is NULL", i);
+    hipStream_t st = (hipStream_t)stream;
+    const nd_config& c = h->cfg;
+    const int H = c.hidden_dim, F = c.feature_dim, T = c.n_steps, C = c.y_dim, D = c.data_dim;
+    MemberHost& m = h->members[k];
+    m.w = *w;
+    auto g1 = [](int n) { return dim3((n + 255) / 256); };
+    hipLaunchKernelGGL(k_fold_bn, g1(H), dim3(256), 0, st, m.sc0, m.sh0, w->enc0_b, w->bn0_w, w->bn0_b, w->bn0_mean, w->bn0_var, H);
+    hipLaunchKernelGGL(k_fold_bn, g1(H), dim3(256), 0, st, m.sc1, m.sh1, w->enc3_b, w->bn1_w, w->bn1_b, w->bn1_mean, w->bn1_var, H);
+    hipLaunchKernelGGL(k_fold_bn, g1(F), dim3(256), 0, st, m.sc2, m.sh2, w->enc6_b, w->norm_w, w->norm_b, w->norm_mean, w->norm_var, F);
+    const float* embs[3] = {w->emb1, w->emb2, w->emb3};
+    const float* lb[3] = {w->lin1_b, w->lin2_b, w->lin3_b};
+    const float* bw[3] = {w->un1_w, w->un2_w, w->un3_w};
+    const float* bb[3] = {w->un1_b, w->un2_b, w->un3_b};
+    const float* bm[3] = {w->un1_mean, w->un2_mean, w->un3_mean};
+    const float* bv[3] = {w->un1_var, w->un2_var, w->un3_var};
+    const size_t tot = (size_t)T * F;
+    for (int l = 0; l < 3; ++l)
+        hipLaunchKernelGGL(k_fold_steps, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, m.A[l], m.Cc[l], embs[l], lb[l],
+                           bw[l], bb[l], bm[l], bv[l], T, F);
+    HIP_CHECK(hipGetLastError());
+
+    MemberDev md{w->lin1_w, w->lin4_b, m.A[0], m.Cc[0], m.xe, m.h1, m.ybuf, m.epart};
+    SkinnyDesc ds[L_COUNT];
+    ds[L_ENC1] = SkinnyDesc{m.e0, w->enc3_w, m.sc1, m.sh1, m.e1, nullptr, nullptr, H, H, C, ND_ACT_SOFTPLUS};
+    ds[L_ENC2] = SkinnyDesc{m.e1, w->enc6_w, m.sc2, m.sh2, m.xe, nullptr, nullptr, H, F, C, ND_ACT_NONE};
+    ds[L_LIN2] = SkinnyDesc{m.h1, w->lin2_w, m.A[1], m.Cc[1], m.h2, nullptr, nullptr, F, F, C, ND_ACT_SOFTPLUS};
+    ds[L_LIN3] = SkinnyDesc{m.h2, w->lin3_w, m.A[2], m.Cc[2], nullptr, w->lin4_w, m.epart, F, F, C, ND_ACT_SOFTPLUS};
+    // small synchronous H2D copies: load time only, never on the sampling path
+    HIP_CHECK(hipStreamSynchronize(st));
+    HIP_CHECK(hipMemcpy(h->members_dev + k, &md, sizeof md, hipMemcpyHostToDevice));
+    for (int l = 0; l < L_COUNT; ++l)
+        HIP_CHECK(hipMemcpy(h->descs_dev + (size_t)l * c.n_members + k, &ds[l], sizeof(SkinnyDesc), hipMemcpyHostToDevice));
+    if (h->enc_splitk) {
+        const int nch = D / 16;
+        SplitKDesc sd{nullptr, w->enc0_w, m.splitk, D, H, h->S0, (nch + h->S0 - 1) / h->S0};
+        SplitKEpiDesc se{m.splitk, m.sc0, m.sh0, m.e0, H, h->S0, ND_ACT_SOFTPLUS};
+        HIP_CHECK(hipMemcpy(h->spk_dev + k, &sd, sizeof sd, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(h->spke_dev + k, &se, sizeof se, hipMemcpyHostToDevice));
+    }
+    m.loaded = true;
+    return ND_OK;
+}
+
+static int check_range(nd_handle_s* h, int m0, int nm) {
+    if (!h || !h->ws) return nd_set_err(ND_ERR_STATE, "workspace not bound");
+    if (m0 < 0 || nm < 1 || m0 + nm > h->cfg.n_members) return nd_set_err(ND_ERR_ARG, "member range [%d,%d) invalid", m0, m0 + nm);
+    for (int k = m0; k < m0 + nm; ++k)
+        if (!h->members[k].loaded) return nd_set_err(ND_ERR_STATE, "member %d not loaded", k);
+    return ND_OK;
+}
+
+template <int MODE>
+static void launch_skinny(const SkinnyDesc* table, int K_unused, int N, int M, int t, int nm, hipStream_t st) {
+    (void)K_unused;
+    const SkinnyDesc d0{};
+    const int mt = nd_pick_mt(M);
+    const dim3 block(256);
+    if (mt == 1) {
+        dim3 grid((N + 15) / 16, (M + 15) / 16, nm);
+        hipLaunchKernelGGL((k_skinny_fused<1, 4, MODE>), grid, block, 0, st, d0, table, M, t);
+    } else if (mt == 2) {
+        dim3 grid((N + 15) / 16, (M + 31) / 32, nm);
+        hipLaunchKernelGGL((k_skinny_fused<2, 4, MODE>), grid, block, 0, st, d0, table, M, t);
+    } else {
+        dim3 grid((N + 15) / 16, (M + 63) / 64, nm);
+        hipLaunchKernelGGL((k_skinny_fused<4, 4, MODE>), grid, block, 0, st, d0, table, M, t);
+    }
+}
+
+template <int MODE>
+static void* skinny_fn(int M) {
+    const int mt = nd_pick_mt(M);
+    if (mt == 1) return (void*)k_skinny_fused<1, 4, MODE>;
+    if (mt == 2) return (void*)k_skinny_fused<2, 4, MODE>;
+    return (void*)k_skinny_fused<4, 4, MODE>;
+}
+static dim3 skinny_grid(int N, int M, int nm) {
+    const int mt = nd_pick_mt(M);
+    return dim3((N + 15) / 16, (M + 16 * mt - 1) / (16 * mt), nm);
+}
+
+extern "C" int nd_encode(nd_handle h, int m0, int nm, const float* x_dev, int B, void* stream) {
+    int rc = check_range(h, m0, nm);
+    if (rc != ND_OK) return rc;
+    if (!x_dev) return nd_set_err(ND_ERR_ARG, "x_dev is NULL");
+    if (B < 1 || B > h->cfg.max_batch) return nd_set_err(ND_ERR_ARG, "B=%d outside [1,%d]", B, h->cfg.max_batch);
+    hipStream_t st = (hipStream_t)stream;
+    const nd_config& c = h->cfg;
+    const int K = c.n_members, H = c.hidden_dim, F = c.feature_dim, D = c.data_dim;
+    if (h->enc_splitk) {
+        // every member reads the same x: patch the descriptors' x pointer via a by-value override
+        for (int k = m0; k < m0 + nm; ++k) {
+            MemberHost& m = h->members[k];
+            const int nch = D / 16;
+            SplitKDesc sd{x_dev, m.w.enc0_w, m.splitk, D, H, h->S0, (nch + h->S0 - 1) / h->S0};
+            const int ntiles = (H + ND_SPK_TILE_N - 1) / ND_SPK_TILE_N;
+            const int mt = B <= 16 ? 1 : (B <= 32 ? 2 : 4);
+            dim3 grid(ntiles * h->S0, (B + 16 * mt - 1) / (16 * mt), 1);
+            if (mt == 1) hipLaunchKernelGGL((k_skinny_splitk<1>), grid, dim3(256), 0, st, sd, (const SplitKDesc*)nullptr, B);
+            else if (mt == 2) hipLaunchKernelGGL((k_skinny_splitk<2>), grid, dim3(256), 0, st, sd, (const SplitKDesc*)nullptr, B);
+            else hipLaunchKernelGGL((k_skinny_splitk<4>), grid, dim3(256), 0, st, sd, (const SplitKDesc*)nullptr, B);
+        }
+        const size_t tot = (size_t)B * H;
+        hipLaunchKernelGGL(k_splitk_epilogue, dim3((unsigned)((tot + 255) / 256), 1, nm), dim3(256), 0, st, SplitKEpiDesc{},
+                           (const SplitKEpiDesc*)(h->spke_dev + m0), B);
+    } else {
+        for (int k = m0; k < m0 + nm; ++k) {
+            MemberHost& m = h->members[k];
+            SkinnyDesc d{x_dev, m.w.enc0_w, m.sc0, m.sh0, m.e0, nullptr, nullptr, D, H, c.y_dim, ND_ACT_SOFTPLUS};
+            const int mt = nd_pick_mt(B);
+            dim3 grid((H + 15) / 16, (B + 16 * mt - 1) / (16 * mt), 1);
+            if (mt == 1) hipLaunchKernelGGL((k_skinny_fused<1, 4, 0>), grid, dim3(256), 0, st, d, (const SkinnyDesc*)nullptr, B, 0);
+            else if (mt == 2) hipLaunchKernelGGL((k_skinny_fused<2, 4, 0>), grid, dim3(256), 0, st, d, (const SkinnyDesc*)nullptr, B, 0);
+            else hipLaunchKernelGGL((k_skinny_fused<4, 4, 0>), grid, dim3(256), 0, st, d, (const SkinnyDesc*)nullptr, B, 0);
+        }
+    }
+    launch_skinny<0>(h->descs_dev + (size_t)L_ENC1 * K + m0, H, H, B, 0, nm, st);
+    launch_skinny<0>(h->descs_dev + (size_t)L_ENC2 * K + m0, H, F, B, 0, nm, st);
+    HIP_CHECK(hipGetLastError());
+    h->encoded_B = B;
+    return ND_OK;
+}
+
+extern "C" int nd_member_buffer(nd_handle h, int k, int which, void** out) {
+    if (!h || !h->ws || !out) return nd_set_err(ND_ERR_ARG, "bad argument");
+    if (k < 0 || k >= h->cfg.n_members) return nd_set_err(ND_ERR_ARG, "member out of range");
+    MemberHost& m = h->members[k];
+    switch (which) {
+        case 0: *out = m.xe; break;
+        case 1: *out = m.h1; break;
+        case 2: *out = m.h2; break;
+        default: return nd_set_err(ND_ERR_ARG, "which=%d unknown", which);
+    }
+    return ND_OK;
+}
+
+extern "C" int nd_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream) {
+    if (!dst || !src) return nd_set_err(ND_ERR_ARG, "NULL pointer");
+    HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return ND_OK;
+}
+
+static int check_rows(nd_handle_s* h, int B, int mc, int T) {
+    if (B < 1 || B > h->cfg.max_batch) return nd_set_err(ND_ERR_ARG, "B=%d outside [1,%d]", B, h->cfg.max_batch);
+    if (mc < 1 || (long)B * mc > h->cfg.max_rows) return nd_set_err(ND_ERR_ARG, "B*mc=%ld exceeds max_rows=%d", (long)B * mc, h->cfg.max_rows);
+    if (T < 1 || T > h->cfg.n_steps) return nd_set_err(ND_ERR_ARG, "T=%d outside [1,%d]", T, h->cfg.n_steps);
+    if (h->sched_T < T) return nd_set_err(ND_ERR_STATE, "schedule holds %d steps, need %d (nd_set_schedule)", h->sched_T, T);
+    if (h->encoded_B != B) return nd_set_err(ND_ERR_STATE, "nd_encode ran with B=%d, sampling asks B=%d", h->encoded_B, B);
+    return ND_OK;
+}
+
+extern "C" int nd_eps_theta(nd_handle h, int member, const float* y_dev, const float* yhat_dev, int t, float* eps_out, int B,
+                            int mc, void* stream) {
+    int rc = check_range(h, member, 1);
+    if (rc != ND_OK) return rc;
+    if (!y_dev || !yhat_dev || !eps_out) return nd_set_err(ND_ERR_ARG, "NULL tensor");
+    if (B < 1 || B > h->cfg.max_batch || mc < 1 || (long)B * mc > h->cfg.max_rows) return nd_set_err(ND_ERR_ARG, "B/mc out of range");
+    if (t < 0 || t >= h->cfg.n_steps) return nd_set_err(ND_ERR_ARG, "t=%d outside [0,%d)", t, h->cfg.n_steps);
+    if (h->encoded_B != B) return nd_set_err(ND_ERR_STATE, "nd_encode ran with B=%d, asked B=%d", h->encoded_B, B);
+    hipStream_t st = (hipStream_t)stream;
+    const nd_config& c = h->cfg;
+    const int K = c.n_members, F = c.feature_dim, C = c.y_dim, M = B * mc;
+    StepIO io{};
+    io.yhat = yhat_dev; io.y_in = y_dev; io.alphas = h->alphas; io.omabs = h->omabs;
+    hipLaunchKernelGGL(k_step_head, dim3((F + 1023) / 1024, M, 1), dim3(256), 0, st, (const MemberDev*)(h->members_dev + member), io,
+                       ND_HEAD_GIVEN, 0, 0, t, B, M, c.max_rows, C, F, h->NT, c.n_steps);
+    launch_skinny<0>(h->descs_dev + (size_t)L_LIN2 * K + member, F, F, M, t, 1, st);
+    launch_skinny<1>(h->descs_dev + (size_t)L_LIN3 * K + member, F, F, M, t, 1, st);
+    hipLaunchKernelGGL(k_step_final, dim3(M, 1, 1), dim3(64), 0, st, (const MemberDev*)(h->members_dev + member), io, 1, 0, B, M,
+                       c.max_rows, C, h->NT, c.n_steps, eps_out, (size_t)0);
+    HIP_CHECK(hipGetLastError());
+    return ND_OK;
+}
+
+// Enqueue (eager) or record (graph) the 3T+1 kernels of one p_sample_loop for a member range.
+struct Emitter {
+    hipStream_t st;
+    hipGraph_t graph = nullptr;
+    hipGraphNode_t last = nullptr;
+    hipError_t err = hipSuccess;
+    void emit(void* fn, dim3 grid, dim3 block, void** args) {
+        if (err != hipSuccess) return;
+        if (!graph) {
+            err = hipLaunchKernel(fn, grid, block, args, 0, st);
+        } else {
+            hipKernelNodeParams p{};
+            p.func = fn; p.gridDim = grid; p.blockDim = block; p.sharedMemBytes = 0; p.kernelParams = args; p.extra = nullptr;
+            hipGraphNode_t node;
+            err = hipGraphAddKernelNode(&node, graph, last ? &last : nullptr, last ? 1 : 0, &p);
+            last = node;
+        }
+    }
+};
+
+static hipError_t emit_loop(nd_handle_s* h, Emitter& em, int m0, int nm, StepIO io, int B, int mc, int T) {
+    const nd_config& c = h->cfg;
+    int K = c.n_members, F = c.feature_dim, C = c.y_dim, M = B * mc, maxM = c.max_rows, NT = h->NT, Tn = T;
+    const MemberDev* mdev = h->members_dev + m0;
+    const SkinnyDesc* t2 = h->descs_dev + (size_t)L_LIN2 * K + m0;
+    const SkinnyDesc* t3 = h->descs_dev + (size_t)L_LIN3 * K + m0;
+    SkinnyDesc d0{};
+    const dim3 ghead((F + 1023) / 1024, M, nm), gsk = skinny_grid(F, M, nm);
+    void* f2 = skinny_fn<0>(M);
+    void* f3 = skinny_fn<1>(M);
+    for (int i = 0; i < T; ++i) {
+        int t = T - 1 - i, t_prev = t + 1, mode = (i == 0) ? ND_HEAD_INIT : ND_HEAD_UPDATE, istep = i;
+        void* ah[] = {&mdev, &io, &mode, &istep, &t_prev, &t, &B, &M, &maxM, &C, &F, &NT, &Tn};
+        em.emit((void*)k_step_head, ghead, dim3(256), ah);
+        void* a2[] = {&d0, &t2, &M, &t};
+        em.emit(f2, gsk, dim3(256), a2);
+        void* a3[] = {&d0, &t3, &M, &t};
+        em.emit(f3, gsk, dim3(256), a3);
+    }
+    int eps_only = 0, par_cur = (T - 1) & 1;
+    float* eps_out = nullptr;
+    size_t eps_ms = 0;
+    void* af[] = {&mdev, &io, &eps_only, &par_cur, &B, &M, &maxM, &C, &NT, &Tn, &eps_out, &eps_ms};
+    em.emit((void*)k_step_final, dim3(M, 1, nm), dim3(64), af);
+    return em.err;
+}
+
+extern "C" int nd_sample(nd_handle h, int m0, int nm, const float* yhat_dev, const float* ymean_dev, const float* noise_dev,
+                         float* y0_out_dev, float* seq_out_dev, int B, int mc, int T, int use_graph, void* stream) {
+    int rc = check_range(h, m0, nm);
+    if (rc != ND_OK) return rc;
+    if (!yhat_dev || !ymean_dev || !noise_dev || !y0_out_dev) return nd_set_err(ND_ERR_ARG, "NULL tensor");
+    rc = check_rows(h, B, mc, T);
+    if (rc != ND_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const int C = h->cfg.y_dim, M = B * mc;
+    StepIO io{};
+    io.yhat = yhat_dev;   io.yhat_ms = (size_t)B * C;
+    io.ymean = ymean_dev; io.ymean_ms = (size_t)B * C;
+    io.noise = noise_dev; io.noise_ms = (size_t)T * M * C;
+    io.y0_out = y0_out_dev; io.y0_ms = (size_t)M * C;
+    io.seq_out = seq_out_dev; io.seq_ms = (size_t)(T + 1) * M * C;
+    io.alphas = h->alphas; io.omabs = h->omabs;
+    if (!use_graph) {
+        Emitter em{st};
+        hipError_t e = emit_loop(h, em, m0, nm, io, B, mc, T);
+        if (e != hipSuccess) return nd_set_err(ND_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+        return ND_OK;
+    }
+    GraphKey key{m0, nm, B, mc, T, yhat_dev, ymean_dev, noise_dev, y0_out_dev, seq_out_dev};
+    auto it = h->graphs.find(key);
+    if (it == h->graphs.end()) {
+        Emitter em{st};
+        HIP_CHECK(hipGraphCreate(&em.graph, 0));
+        hipError_t e = emit_loop(h, em, m0, nm, io, B, mc, T);
+        if (e != hipSuccess) {
+            (void)hipGraphDestroy(em.graph);
+            return nd_set_err(ND_ERR_HIP, "graph build failed: %s", hipGetErrorString(e));
+        }
+        hipGraphExec_t exec;
+        e = hipGraphInstantiate(&exec, em.graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(em.graph);
+        if (e != hipSuccess) return nd_set_err(ND_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e));
+        if (h->graphs.size() >= 64) drop_graphs(h);
+        it = h->graphs.emplace(key, exec).first;
+    }
+    HIP_CHECK(hipGraphLaunch(it->second, st));
+    return ND_OK;
+}

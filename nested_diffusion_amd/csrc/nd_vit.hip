@@ -1,0 +1,359 @@
+// nd_vit.hip -- kernels for the ViT prefix of the mapping network (timm 0.4.12 vit_base_patch16_224
+// semantics; call sites classification_train_separately.py:337-340).  gfx950 only, fp32 with
+// f32-input MFMA (exact f32 products).
+#include "nd_common.hpp"
+#include "../../include/nested_diffusion.h"
+
+int nd_set_err(int code, const char* fmt, ...);
+#define HIP_CHECK(expr)                                                                              \
+    do {                                                                                             \
+        hipError_t _e = (expr);                                                                      \
+        if (_e != hipSuccess)                                                                        \
+            return nd_set_err(ND_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// Large-M GEMM, both operands K-contiguous:  out[m,n] = act(sum_k x[m,k] w[n,k] + bias[n]) + res[m,n]
+// Workgroup tile BM x BN (256 threads = 2x2 waves), BK = 16 per stage, two LDS stages filled through
+// registers (loads for stage s+1 issued before the MFMAs of stage s, written after them).
+// LDS rows are 16 floats + 4 pad so a lane's float4 (k = 4*(l>>4)..+3) is one ds_read_b128; MFMA jj
+// takes element jj of every lane (k order permuted identically on both operands).
+// ---------------------------------------------------------------------------------------------
+#define GB_K 16
+#define GB_LD 20
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void k_gemm_nt(const float* __restrict__ x, const float* __restrict__ w,
+                                                 const float* __restrict__ bias, const float* __restrict__ res,
+                                                 float* __restrict__ out, int M, int K, int N, int act) {
+    constexpr int WM = BM / 2, WN = BN / 2;      // per-wave tile
+    constexpr int FM = WM / 16, FN = WN / 16;    // 16x16 fragments per wave
+    constexpr int LA = BM * GB_K / 4 / 256;      // float4 loads per thread for the x tile
+    constexpr int LB = BN * GB_K / 4 / 256;
+    static_assert(LA >= 1 && LB >= 1, "tile too small");
+    __shared__ __attribute__((aligned(16))) float sA[2][BM][GB_LD];
+    __shared__ __attribute__((aligned(16))) float sB[2][BN][GB_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    // XCD-aware tile order: consecutive tiles along N (sharing the x panel) land on one XCD
+    const int tiles_n = (N + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
+    const int nwg = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, loc = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int tm = bid / tiles_n, tn = bid % tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // staging map: thread -> (row, kq) with 4 threads per 16-float row
+    float4 ra[LA], rb[LB];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < LA; ++i) {
+            const int e = tid + i * 256, row = e >> 2, kq = (e & 3) * 4;
+            const int gm = min(m0 + row, M - 1);
+            ra[i] = *reinterpret_cast<const float4*>(x + (size_t)gm * K + k0 + kq);
+        }
+#pragma unroll
+        for (int i = 0; i < LB; ++i) {
+            const int e = tid + i * 256, row = e >> 2, kq = (e & 3) * 4;
+            const int gn = min(n0 + row, N - 1);
+            rb[i] = *reinterpret_cast<const float4*>(w + (size_t)gn * K + k0 + kq);
+        }
+    };
+    auto swrite = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < LA; ++i) {
+            const int e = tid + i * 256, row = e >> 2, kq = (e & 3) * 4;
+            *reinterpret_cast<float4*>(&sA[buf][row][kq]) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < LB; ++i) {
+            const int e = tid + i * 256, row = e >> 2, kq = (e & 3) * 4;
+            *reinterpret_cast<float4*>(&sB[buf][row][kq]) = rb[i];
+        }
+    };
+
+    const int nk = K / GB_K;
+    gload(0);
+    swrite(0);
+    __syncthreads();
+    const int lr = lane & 15, lk = 4 * (lane >> 4);
+    for (int ks = 0; ks < nk; ++ks) {
+        const int buf = ks & 1;
+        if (ks + 1 < nk) gload((ks + 1) * GB_K);
+        float4 fa[FM], fb[FN];
+#pragma unroll
+        for (int i = 0; i < FM; ++i) fa[i] = *reinterpret_cast<const float4*>(&sA[buf][wr * WM + 16 * i + lr][lk]);
+#pragma unroll
+        for (int j = 0; j < FN; ++j) fb[j] = *reinterpret_cast<const float4*>(&sB[buf][wc * WN + 16 * j + lr][lk]);
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            const float av[4] = {fa[i].x, fa[i].y, fa[i].z, fa[i].w};
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const float bv[4] = {fb[j].x, fb[j].y, fb[j].z, fb[j].w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q)  // A = w rows (n), B = x rows (m): D[i=n][j=m]
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[q], av[q], acc[i][j], 0, 0, 0);
+            }
+        }
+        if (ks + 1 < nk) {
+            swrite(buf ^ 1);
+            __syncthreads();
+        }
+    }
+    // D[n = 4*(l>>4)+r][m = l&15]: a lane owns 4 consecutive n of one row m
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        const int m = m0 + wr * WM + 16 * i + (lane & 15);
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const int n = n0 + wc * WN + 16 * j + 4 * (lane >> 4);
+            if (m < M && n < N) {
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int nn = min(n + r, N - 1);
+                    float t = acc[i][j][r] + (bias ? bias[nn] : 0.f);
+                    t = nd_act(t, act);
+                    if (res && n + r < N) t += res[(size_t)m * N + n + r];
+                    v[r] = t;
+                }
+                float* p = out + (size_t)m * N + n;
+                if (n + 3 < N && (N & 3) == 0) *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+                else for (int r = 0; r < 4 && n + r < N; ++r) p[r] = v[r];
+            }
+        }
+    }
+}
+
+extern "C" int nd_gemm_bias_act(const float* x, const float* w, const float* bias, const float* res, float* out, int M, int K,
+                                int N, int act, void* stream) {
+    if (!x || !w || !out) return nd_set_err(ND_ERR_ARG, "NULL tensor");
+    if (M < 1 || N < 1 || K < 16 || (K % 16)) return nd_set_err(ND_ERR_ARG, "need M,N >= 1 and K a positive multiple of 16 (K=%d)", K);
+    if (act < 0 || act > 3) return nd_set_err(ND_ERR_ARG, "unknown activation %d", act);
+    hipStream_t st = (hipStream_t)stream;
+    const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+    if (t128 >= 512) {
+        hipLaunchKernelGGL((k_gemm_nt<128, 128>), dim3((unsigned)t128), dim3(256), 0, st, x, w, bias, res, out, M, K, N, act);
+    } else {
+        const long t = (long)((M + 127) / 128) * ((N + 63) / 64);
+        hipLaunchKernelGGL((k_gemm_nt<128, 64>), dim3((unsigned)t), dim3(256), 0, st, x, w, bias, res, out, M, K, N, act);
+    }
+    HIP_CHECK(hipGetLastError());
+    return ND_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm over the last dim; one wave per row, two-pass (mean, then centred variance) in registers.
+// ---------------------------------------------------------------------------------------------
+template <int VPL>  // float4 per lane: dim <= 64*4*VPL
+__global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                   const float* __restrict__ beta, float* __restrict__ out, int rows, int dim,
+                                                   float eps) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* p = x + (size_t)row * dim;
+    float4 v[VPL];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        v[i] = c < dim ? *reinterpret_cast<const float4*>(p + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    const float mean = s / (float)dim;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < dim) {
+            const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+            q += (a * a + b * b) + (cc * cc + d * d);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off, 64);
+    const float rstd = 1.0f / sqrtf(q / (float)dim + eps);
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < dim) {
+            const float4 g = *reinterpret_cast<const float4*>(gamma + c);
+            const float4 b = *reinterpret_cast<const float4*>(beta + c);
+            float4 o;
+            o.x = (v[i].x - mean) * rstd * g.x + b.x;
+            o.y = (v[i].y - mean) * rstd * g.y + b.y;
+            o.z = (v[i].z - mean) * rstd * g.z + b.z;
+            o.w = (v[i].w - mean) * rstd * g.w + b.w;
+            *reinterpret_cast<float4*>(out + (size_t)row * dim + c) = o;
+        }
+    }
+}
+
+extern "C" int nd_layernorm(const float* x, const float* gamma, const float* beta, float* out, int rows, int dim, float eps,
+                            void* stream) {
+    if (!x || !gamma || !beta || !out) return nd_set_err(ND_ERR_ARG, "NULL tensor");
+    if (rows < 1 || dim < 4 || (dim % 4) || dim > 64 * 4 * 8) return nd_set_err(ND_ERR_ARG, "dim must be a multiple of 4 in [4,2048]");
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((rows + 3) / 4), block(256);
+    const int vpl = (dim + 255) / 256;
+    if (vpl <= 1) hipLaunchKernelGGL((k_layernorm<1>), grid, block, 0, st, x, gamma, beta, out, rows, dim, eps);
+    else if (vpl <= 2) hipLaunchKernelGGL((k_layernorm<2>), grid, block, 0, st, x, gamma, beta, out, rows, dim, eps);
+    else if (vpl <= 3) hipLaunchKernelGGL((k_layernorm<3>), grid, block, 0, st, x, gamma, beta, out, rows, dim, eps);
+    else if (vpl <= 4) hipLaunchKernelGGL((k_layernorm<4>), grid, block, 0, st, x, gamma, beta, out, rows, dim, eps);
+    else hipLaunchKernelGGL((k_layernorm<8>), grid, block, 0, st, x, gamma, beta, out, rows, dim, eps);
+    HIP_CHECK(hipGetLastError());
+    return ND_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Attention core for d = 64.  One wave per 16 query rows of one (batch, head); K/V fragments come
+// straight from L2 as MFMA operands (each K/V row is 256 contiguous bytes).
+//   S^T = K Q^T   : A = K[key=16f+(l&15)][d=16c+4g+jj], B = Q[q=l&15][same d]  -> D[key=16f+4g+r][q=l&15]
+//   softmax over keys: in-lane over (f, r), across the 4 lane groups g by xor 16/32.
+//   O^T = V^T P^T : the k-step (f, r) takes key 16f+4g+r from lane group g -- exactly the S^T
+//                   register acc[f][r] of that lane -- and A = V[key][4*(l&15)+e] (float4, e = d-frag),
+//                   so no transpose or LDS is needed.  D_e[i=4g'+r'][q] holds d = 4*i + e.
+// ---------------------------------------------------------------------------------------------
+#define AT_MAXF 16  // up to 256 keys
+template <int NF>
+__global__ __launch_bounds__(256) void k_attention_d64(const float* __restrict__ qkv, float* __restrict__ out, int B, int N,
+                                                       int heads) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int qf = blockIdx.x * 4 + wave;                 // 16-row query fragment
+    const int bh = blockIdx.y, b = bh / heads, hd = bh % heads;
+    if (qf * 16 >= N) return;
+    const int Cm = heads * 64;
+    const size_t rs = (size_t)3 * Cm;                      // token stride in qkv
+    const float* base = qkv + (size_t)b * N * rs + (size_t)hd * 64;
+    const float* qb = base;                                // q: [.., 0, hd, :]
+    const float* kb = base + Cm;
+    const float* vb = base + 2 * Cm;
+    const int g = lane >> 4, li = lane & 15;
+    const int qrow = min(qf * 16 + li, N - 1);
+    float4 qv[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) qv[c] = *reinterpret_cast<const float4*>(qb + (size_t)qrow * rs + 16 * c + 4 * g);
+
+    f32x4 s[NF];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+        s[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int krow = min(16 * f + li, N - 1);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float4 kv = *reinterpret_cast<const float4*>(kb + (size_t)krow * rs + 16 * c + 4 * g);
+            s[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(kv.x, qv[c].x, s[f], 0, 0, 0);
+            s[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(kv.y, qv[c].y, s[f], 0, 0, 0);
+            s[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(kv.z, qv[c].z, s[f], 0, 0, 0);
+            s[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(kv.w, qv[c].w, s[f], 0, 0, 0);
+        }
+    }
+    // scale, mask invalid keys, softmax over keys (per query column q = lane & 15)
+    const float scale = 0.125f;  // 64^-0.5
+    float mx = -INFINITY;
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int key = 16 * f + 4 * g + r;
+            const float v = key < N ? s[f][r] * scale : -INFINITY;
+            s[f][r] = v;
+            mx = fmaxf(mx, v);
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float p = expf(s[f][r] - mx);
+            s[f][r] = p;
+            sum += p;
+        }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+
+    f32x4 o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int key = min(16 * f + 4 * g + r, N - 1);
+            const float4 vv = *reinterpret_cast<const float4*>(vb + (size_t)key * rs + 4 * li);
+            const float p = s[f][r] * inv;     // normalised first, as torch (softmax then @ v)
+            o[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv.x, p, o[0], 0, 0, 0);
+            o[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv.y, p, o[1], 0, 0, 0);
+            o[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv.z, p, o[2], 0, 0, 0);
+            o[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv.w, p, o[3], 0, 0, 0);
+        }
+    // o[e][r'] = O[q = l&15][d = 4*(4g + r') + e]  ->  float4 over e at d0 = 16g + 4r'
+    const int qo = qf * 16 + li;
+    if (qo < N) {
+        float* op = out + ((size_t)b * N + qo) * Cm + (size_t)hd * 64 + 16 * g;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) *reinterpret_cast<float4*>(op + 4 * r) = make_float4(o[0][r], o[1][r], o[2][r], o[3][r]);
+    }
+}
+
+extern "C" int nd_attention(const float* qkv, float* out, int B, int N, int heads, int d, void* stream) {
+    if (!qkv || !out) return nd_set_err(ND_ERR_ARG, "NULL tensor");
+    if (d != 64) return nd_set_err(ND_ERR_ARG, "head dim must be 64 (got %d)", d);
+    if (B < 1 || heads < 1 || N < 1 || N > 16 * AT_MAXF) return nd_set_err(ND_ERR_ARG, "need 1 <= N <= %d", 16 * AT_MAXF);
+    hipStream_t st = (hipStream_t)stream;
+    const int nf = (N + 15) / 16;
+    const dim3 grid((nf + 3) / 4, B * heads), block(256);
+#define AT_CASE(NFV) case NFV: hipLaunchKernelGGL((k_attention_d64<NFV>), grid, block, 0, st, qkv, out, B, N, heads); break;
+    switch (nf) {
+        AT_CASE(1) AT_CASE(2) AT_CASE(3) AT_CASE(4) AT_CASE(5) AT_CASE(6) AT_CASE(7) AT_CASE(8)
+        AT_CASE(9) AT_CASE(10) AT_CASE(11) AT_CASE(12) AT_CASE(13) AT_CASE(14) AT_CASE(15) AT_CASE(16)
+    }
+#undef AT_CASE
+    HIP_CHECK(hipGetLastError());
+    return ND_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// im2col for Conv2d(k = p, stride = p): cols[(b, py, px)][c*p*p + iy*p + ix] = img[b][c][py*p+iy][px*p+ix]
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_patchify(const float* __restrict__ img, float* __restrict__ cols, int B, int Cin,
+                                                  int Himg, int Wimg, int p) {
+    const int gw = Wimg / p, gh = Himg / p;
+    const size_t rowlen = (size_t)Cin * p * p;
+    const size_t total4 = (size_t)B * gh * gw * rowlen / 4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t e = i * 4;
+        const size_t tok = e / rowlen;
+        const int col = (int)(e % rowlen);
+        const int c = col / (p * p), iy = (col / p) % p, ix = col % p;
+        const int b = (int)(tok / (gh * gw)), py = (int)(tok % (gh * gw)) / gw, px = (int)(tok % gw);
+        const float4 v = *reinterpret_cast<const float4*>(img + (((size_t)b * Cin + c) * Himg + (py * p + iy)) * Wimg + px * p + ix);
+        *reinterpret_cast<float4*>(cols + e) = v;
+    }
+}
+
+extern "C" int nd_patchify(const float* img, float* cols, int B, int Cin, int Himg, int Wimg, int p, void* stream) {
+    if (!img || !cols) return nd_set_err(ND_ERR_ARG, "NULL tensor");
+    if (B < 1 || Cin < 1 || p < 4 || (p % 4) || Himg % p || Wimg % p || (Wimg % 4))
+        return nd_set_err(ND_ERR_ARG, "patch size must be a multiple of 4 dividing the image");
+    const size_t total4 = (size_t)B * Cin * Himg * Wimg / 4;
+    const unsigned blocks = (unsigned)((total4 + 255) / 256 > 4096 ? 4096 : (total4 + 255) / 256);
+    hipLaunchKernelGGL(k_patchify, dim3(blocks), dim3(256), 0, (hipStream_t)stream, img, cols, B, Cin, Himg, Wimg, p);
+    HIP_CHECK(hipGetLastError());
+    return ND_OK;
+}

@@ -1,0 +1,166 @@
+"""Host-side owner of one nd_handle: device memory (torch tensors), streams, and the calls into
+libnd_hip.so.  PyTorch is plumbing here -- all arithmetic of the hot path runs in the HIP library.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import MEMBER_WEIGHT_FIELDS, NdConfig, NdMemberWeights, check, ptr
+
+
+def _require_gpu(device) -> torch.device:
+    device = torch.device(device)
+    if device.type != "cuda" or not torch.cuda.is_available():
+        raise _lib.NdError("nested_diffusion_amd needs an MI355X (torch device 'cuda'); there is no CPU fallback")
+    return device
+
+
+class EnsembleEngine:
+    """K ConditionalModel members (latent_model.py:108-167) resident on one GPU.
+
+    Replaces the reference's per-batch load/.to(device)/.to(cpu) shuttle of each noise estimator
+    (classification_train_separately.py:685-697, 773, 780): all members stay in HBM.
+    """
+
+    def __init__(self, y_dim: int, data_dim: int, hidden_dim: int, feature_dim: int, n_steps: int,
+                 n_members: int = 1, max_batch: int = 32, max_rows: Optional[int] = None, device="cuda"):
+        self.device = _require_gpu(device)
+        self.lib = _lib.load()
+        max_rows = max_rows if max_rows is not None else max_batch
+        self.cfg = NdConfig(y_dim, data_dim, hidden_dim, feature_dim, n_steps, n_members, max_batch, max_rows)
+        self.C, self.D, self.H, self.F, self.T, self.K = y_dim, data_dim, hidden_dim, feature_dim, n_steps, n_members
+        self.max_batch, self.max_rows = max_batch, max_rows
+        h = C.c_void_p()
+        check(self.lib.nd_create(C.byref(self.cfg), C.byref(h)), "nd_create")
+        self.h = h
+        nbytes = self.lib.nd_workspace_bytes(C.byref(self.cfg))
+        if nbytes == 0:
+            raise _lib.NdError("nd_workspace_bytes: " + self.lib.nd_last_error().decode())
+        with torch.cuda.device(self.device):
+            self.workspace = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
+        base = (self.workspace.data_ptr() + 255) & ~255
+        check(self.lib.nd_bind_workspace(self.h, base, nbytes), "nd_bind_workspace")
+        self._weights: Dict[int, Dict[str, torch.Tensor]] = {}
+        self._sched: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
+        self._static: Dict[tuple, Dict[str, torch.Tensor]] = {}
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.nd_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    # -- stream ------------------------------------------------------------------------------
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _dev(self, t: torch.Tensor) -> torch.Tensor:
+        return t.detach().to(device=self.device, dtype=torch.float32).contiguous()
+
+    # -- weights -----------------------------------------------------------------------------
+    def load_member(self, k: int, state_dict: Dict[str, torch.Tensor]) -> None:
+        """state_dict = ConditionalModel.state_dict() (checkpoint key 'noise_estimator',
+        classification_train_separately.py:689-690).  Shapes are checked strictly."""
+        C_, D, H, F, T = self.C, self.D, self.H, self.F, self.T
+        want = {"encoder_x.0.weight": (H, D), "encoder_x.3.weight": (H, H), "encoder_x.6.weight": (F, H),
+                "lin1.lin.weight": (F, 2 * C_), "lin2.lin.weight": (F, F), "lin3.lin.weight": (F, F),
+                "lin4.weight": (C_, F), "lin4.bias": (C_,)}
+        for name in ("lin1", "lin2", "lin3"):
+            want[name + ".embed.weight"] = (T + 1, F)
+        held: Dict[str, torch.Tensor] = {}
+        w = NdMemberWeights()
+        for field, key in MEMBER_WEIGHT_FIELDS:
+            if key not in state_dict:
+                raise KeyError(f"state_dict is missing '{key}'")
+            t = self._dev(state_dict[key])
+            if key in want and tuple(t.shape) != want[key]:
+                raise ValueError(f"'{key}' has shape {tuple(t.shape)}, expected {want[key]}")
+            held[key] = t
+            setattr(w, field, t.data_ptr())
+        self._weights[k] = held            # keep the device tensors alive: the library holds raw pointers
+        check(self.lib.nd_load_member(self.h, k, C.byref(w), self._stream()), "nd_load_member")
+
+    def set_schedule(self, alphas: torch.Tensor, one_minus_alphas_bar_sqrt: torch.Tensor) -> None:
+        a, s = self._dev(alphas), self._dev(one_minus_alphas_bar_sqrt)
+        if a.numel() != s.numel():
+            raise ValueError("alphas and one_minus_alphas_bar_sqrt differ in length")
+        self._sched = (a, s)
+        check(self.lib.nd_set_schedule(self.h, ptr(a), ptr(s), a.numel(), self._stream()), "nd_set_schedule")
+
+    # -- compute -----------------------------------------------------------------------------
+    def encode(self, x: torch.Tensor, member0: int = 0, n_members: Optional[int] = None) -> None:
+        """xe = norm(encoder_x(x)) for a member range, cached in the workspace (latent_model.py:170-171)."""
+        n_members = self.K - member0 if n_members is None else n_members
+        x = self._dev(x)
+        if x.dim() != 2 or x.shape[1] != self.D:
+            raise ValueError(f"x must be [B, {self.D}], got {tuple(x.shape)}")
+        check(self.lib.nd_encode(self.h, member0, n_members, ptr(x), x.shape[0], self._stream()), "nd_encode")
+        self._x_keepalive = x
+
+    def member_buffer(self, k: int, which: int, rows: int) -> torch.Tensor:
+        """Copy of an internal buffer: which = 0 xe [rows,F], 1 h1, 2 h2 (tests only)."""
+        p = C.c_void_p()
+        check(self.lib.nd_member_buffer(self.h, k, which, C.byref(p)), "nd_member_buffer")
+        out = torch.empty(rows, self.F, dtype=torch.float32, device=self.device)
+        check(self.lib.nd_memcpy_d2d(ptr(out), p, out.numel() * 4, self._stream()), "nd_memcpy_d2d")
+        return out
+
+    def eps_theta(self, member: int, y: torch.Tensor, yhat: torch.Tensor, t: int, mc: int = 1) -> torch.Tensor:
+        """ConditionalModel.forward's t-dependent trunk on the cached xe (latent_model.py:172-184)."""
+        y, yhat = self._dev(y), self._dev(yhat)
+        B = yhat.shape[0]
+        if y.shape != (B * mc, self.C):
+            raise ValueError(f"y must be [{B * mc}, {self.C}]")
+        out = torch.empty_like(y)
+        check(self.lib.nd_eps_theta(self.h, member, ptr(y), ptr(yhat), int(t), ptr(out), B, mc, self._stream()), "nd_eps_theta")
+        return out
+
+    def static_buffers(self, n_members: int, B: int, mc: int, T: int, seq: bool) -> Dict[str, torch.Tensor]:
+        """Fixed-address I/O tensors so the hipGraph of a (members, B, mc, T) shape is built once."""
+        key = (n_members, B, mc, T, seq)
+        buf = self._static.get(key)
+        if buf is None:
+            M, C_ = B * mc, self.C
+            dev = self.device
+            buf = {"yhat": torch.empty(n_members, B, C_, device=dev), "ymean": torch.empty(n_members, B, C_, device=dev),
+                   "noise": torch.empty(n_members, T, M, C_, device=dev), "y0": torch.empty(n_members, M, C_, device=dev)}
+            if seq:
+                buf["seq"] = torch.empty(n_members, T + 1, M, C_, device=dev)
+            self._static[key] = buf
+        return buf
+
+    def sample(self, yhat: torch.Tensor, ymean: torch.Tensor, noise: torch.Tensor, member0: int = 0,
+               n_members: Optional[int] = None, mc: int = 1, T: Optional[int] = None, return_seq: bool = False,
+               use_graph: bool = True) -> torch.Tensor:
+        """p_sample_loop for a member range x mc trials (diffusion_utils.py:133-163).
+        yhat, ymean: [n_members, B, C]; noise: [n_members, T, B*mc, C] in the reference's draw order.
+        Returns y_0 [n_members, B*mc, C] (or the whole trajectory [n_members, T+1, B*mc, C])."""
+        n_members = self.K - member0 if n_members is None else n_members
+        T = self.T if T is None else T
+        if yhat.dim() != 3 or yhat.shape[0] != n_members or yhat.shape[2] != self.C:
+            raise ValueError(f"yhat must be [{n_members}, B, {self.C}], got {tuple(yhat.shape)}")
+        B = yhat.shape[1]
+        M = B * mc
+        if tuple(ymean.shape) != tuple(yhat.shape):
+            raise ValueError("ymean must have yhat's shape")
+        if tuple(noise.shape) != (n_members, T, M, self.C):
+            raise ValueError(f"noise must be [{n_members}, {T}, {M}, {self.C}], got {tuple(noise.shape)}")
+        if use_graph:
+            buf = self.static_buffers(n_members, B, mc, T, return_seq)
+            buf["yhat"].copy_(yhat); buf["ymean"].copy_(ymean); buf["noise"].copy_(noise)
+            yh, ym, nz, y0 = buf["yhat"], buf["ymean"], buf["noise"], buf["y0"]
+            seq = buf.get("seq")
+        else:
+            yh, ym, nz = self._dev(yhat), self._dev(ymean), self._dev(noise)
+            y0 = torch.empty(n_members, M, self.C, device=self.device)
+            seq = torch.empty(n_members, T + 1, M, self.C, device=self.device) if return_seq else None
+        check(self.lib.nd_sample(self.h, member0, n_members, ptr(yh), ptr(ym), ptr(nz), ptr(y0), ptr(seq), B, mc, T,
+                                 1 if use_graph else 0, self._stream()), "nd_sample")
+        out = seq if return_seq else y0
+        return out.clone() if use_graph else out
