@@ -104,6 +104,12 @@ int nd_encode(nd_handle h, int member0, int n_members, const float *x_dev, int B
 int nd_eps_theta(nd_handle h, int member, const float *y_dev, const float *yhat_dev, int t,
                  float *eps_out_dev, int B, int mc, void *stream);
 
+/* One reverse step for one member: p_sample (diffusion_utils.py:54-92) when t >= 1 with the draw
+ * z_dev [M,C] supplied, p_sample_t_1to0 (:96-111) when t == 0 (z_dev ignored, may be NULL).
+ * y_dev [M,C] -> y_out_dev [M,C]; yhat_dev / ymean_dev [B,C]. */
+int nd_p_sample(nd_handle h, int member, const float *y_dev, const float *yhat_dev, const float *ymean_dev,
+                const float *z_dev, int t, float *y_out_dev, int B, int mc, void *stream);
+
 /* p_sample_loop(..., only_last_sample=True) for members [member0, member0+n_members) and mc
  * Monte-Carlo trials at once (diffusion_utils.py:133-163 driven by the member x trial loop at
  * classification_train_separately.py:767-777).  M = B*mc rows per member, row m = trial*B + image.

@@ -61,6 +61,7 @@ SIGNATURES = {
     "nd_set_schedule": (_i, [_vp, _vp, _vp, _i, _vp]),
     "nd_encode": (_i, [_vp, _i, _i, _vp, _i, _vp]),
     "nd_eps_theta": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i, _i, _vp]),
+    "nd_p_sample": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _vp]),
     "nd_sample": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "nd_member_buffer": (_i, [_vp, _i, _i, C.POINTER(_vp)]),
     "nd_memcpy_d2d": (_i, [_vp, _vp, _sz, _vp]),

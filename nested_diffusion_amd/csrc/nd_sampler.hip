@@ -171,6 +171,8 @@ __global__ __launch_bounds__(256) void k_step_head(const MemberDev* __restrict__
 
 // Last step (t = 0): y_0 = y_0_reparam (diffusion_utils.py:96-111), or plain eps output for the
 // eps_theta entry point.  Grid (M, 1, members), 64 threads.
+// eps_only: 0 = y_0 of the loop, 1 = eps output, 2 = one p_sample step from io.y_in with the draw in
+// io.noise (t = par_cur), 3 = p_sample_t_1to0 from io.y_in.
 __global__ __launch_bounds__(64) void k_step_final(const MemberDev* __restrict__ members, StepIO io, int eps_only, int par_cur,
                                                    int B, int M, int maxM, int C, int NT, int T, float* eps_out, size_t eps_ms) {
     const MemberDev mb = members[blockIdx.z];
@@ -179,8 +181,15 @@ __global__ __launch_bounds__(64) void k_step_final(const MemberDev* __restrict__
     for (int c = 0; c < C; ++c) {
         const float eps = nd_reduce_eps<64>(mb.epart, NT, M, m, C, c, red) + mb.lin4_b[c];
         if (threadIdx.x == 0) {
-            if (eps_only) {
+            if (eps_only == 1) {
                 eps_out[z * eps_ms + (size_t)m * C + c] = eps;
+            } else if (eps_only >= 2) {
+                const float y = io.y_in[(size_t)m * C + c];
+                const float ymean = io.ymean[(size_t)b * C + c];
+                const int t = par_cur;
+                eps_out[(size_t)m * C + c] = eps_only == 2
+                    ? nd_posterior(y, ymean, eps, io.noise[(size_t)m * C + c], io.alphas[t], io.omabs[t], io.omabs[t - 1])
+                    : nd_y0_reparam(y, ymean, eps, io.omabs[0]);
             } else {
                 const float y = mb.ybuf[((size_t)par_cur * maxM + m) * C + c];
                 const float ymean = io.ymean[z * io.ymean_ms + (size_t)b * C + c];
@@ -540,6 +549,29 @@ extern "C" int nd_eps_theta(nd_handle h, int member, const float* y_dev, const f
     launch_skinny<1>(h->descs_dev + (size_t)L_LIN3 * K + member, F, F, M, t, 1, st);
     hipLaunchKernelGGL(k_step_final, dim3(M, 1, 1), dim3(64), 0, st, (const MemberDev*)(h->members_dev + member), io, 1, 0, B, M,
                        c.max_rows, C, h->NT, c.n_steps, eps_out, (size_t)0);
+    HIP_CHECK(hipGetLastError());
+    return ND_OK;
+}
+
+extern "C" int nd_p_sample(nd_handle h, int member, const float* y_dev, const float* yhat_dev, const float* ymean_dev,
+                           const float* z_dev, int t, float* y_out, int B, int mc, void* stream) {
+    int rc = check_range(h, member, 1);
+    if (rc != ND_OK) return rc;
+    if (!y_dev || !yhat_dev || !ymean_dev || !y_out) return nd_set_err(ND_ERR_ARG, "NULL tensor");
+    if (t > 0 && !z_dev) return nd_set_err(ND_ERR_ARG, "z_dev is required for t >= 1");
+    rc = check_rows(h, B, mc, t + 1);
+    if (rc != ND_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const nd_config& c = h->cfg;
+    const int K = c.n_members, F = c.feature_dim, C = c.y_dim, M = B * mc;
+    StepIO io{};
+    io.yhat = yhat_dev; io.ymean = ymean_dev; io.y_in = y_dev; io.noise = z_dev; io.alphas = h->alphas; io.omabs = h->omabs;
+    hipLaunchKernelGGL(k_step_head, dim3((F + 1023) / 1024, M, 1), dim3(256), 0, st, (const MemberDev*)(h->members_dev + member), io,
+                       ND_HEAD_GIVEN, 0, 0, t, B, M, c.max_rows, C, F, h->NT, c.n_steps);
+    launch_skinny<0>(h->descs_dev + (size_t)L_LIN2 * K + member, F, F, M, t, 1, st);
+    launch_skinny<1>(h->descs_dev + (size_t)L_LIN3 * K + member, F, F, M, t, 1, st);
+    hipLaunchKernelGGL(k_step_final, dim3(M, 1, 1), dim3(64), 0, st, (const MemberDev*)(h->members_dev + member), io, t > 0 ? 2 : 3, t, B,
+                       M, c.max_rows, C, h->NT, c.n_steps, y_out, (size_t)0);
     HIP_CHECK(hipGetLastError());
     return ND_OK;
 }

@@ -1,0 +1,70 @@
+"""Multi-GPU: one process per GPU (torch.distributed; backend 'nccl' = RCCL over xGMI on ROCm).
+
+The path shards with no data-path collective: every (image, member, trial) sample is independent, so
+the test batch is split across ranks, every rank holds all K members, and the only exchange is ONE
+all-gather of the per-image results at the end of a batch.  CPU tests run the same code
+over the gloo backend.
+"""
+from __future__ import annotations
+
+import os
+from typing import Tuple
+
+import torch
+import torch.distributed as td
+
+
+def rank_world() -> Tuple[int, int]:
+    if td.is_available() and td.is_initialized():
+        return td.get_rank(), td.get_world_size()
+    return 0, 1
+
+
+def init_from_env(backend: str = None) -> Tuple[int, int, int]:
+    """Initialise from torchrun's env (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).  Returns
+    (rank, local_rank, world).  No-op for single-process runs."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not td.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            td.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            td.init_process_group(backend, rank=rank, world_size=world)
+    return rank, local, world
+
+
+def shard_bounds(n: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous, balanced split of n rows: the first n % world ranks get one extra row."""
+    if world < 1 or not (0 <= rank < world):
+        raise ValueError(f"bad rank/world {rank}/{world}")
+    q, r = divmod(n, world)
+    lo = rank * q + min(rank, r)
+    return lo, lo + q + (1 if rank < r else 0)
+
+
+def all_gather_rows(local: torch.Tensor, n_total: int, world: int = None) -> torch.Tensor:
+    """Concatenate the ranks' row shards (dim 0) in rank order with one all_gather.  Shards may be
+    ragged by one row (shard_bounds); they are padded to the widest shard for the collective."""
+    rank, w = rank_world()
+    world = w if world is None else world
+    if world == 1:
+        return local
+    q, r = divmod(n_total, world)
+    widest = q + (1 if r else 0)
+    pad = torch.zeros((widest,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    out = torch.empty((world * widest,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    td.all_gather_into_tensor(out, pad)
+    if r == 0:
+        return out
+    pieces = []
+    for k in range(world):
+        lo, hi = shard_bounds(n_total, k, world)
+        pieces.append(out[k * widest: k * widest + (hi - lo)])
+    return torch.cat(pieces, dim=0)

@@ -121,6 +121,18 @@ class EnsembleEngine:
         check(self.lib.nd_eps_theta(self.h, member, ptr(y), ptr(yhat), int(t), ptr(out), B, mc, self._stream()), "nd_eps_theta")
         return out
 
+    def p_sample(self, member: int, y: torch.Tensor, yhat: torch.Tensor, ymean: torch.Tensor, t: int,
+                 z: Optional[torch.Tensor] = None, mc: int = 1) -> torch.Tensor:
+        """One reverse step: p_sample (t >= 1, draw z supplied) or p_sample_t_1to0 (t == 0)
+        -- diffusion_utils.py:54-111."""
+        y, yhat, ymean = self._dev(y), self._dev(yhat), self._dev(ymean)
+        z = self._dev(z) if z is not None else None
+        B = yhat.shape[0]
+        out = torch.empty_like(y)
+        check(self.lib.nd_p_sample(self.h, member, ptr(y), ptr(yhat), ptr(ymean), ptr(z), int(t), ptr(out), B, mc,
+                                   self._stream()), "nd_p_sample")
+        return out
+
     def static_buffers(self, n_members: int, B: int, mc: int, T: int, seq: bool) -> Dict[str, torch.Tensor]:
         """Fixed-address I/O tensors so the hipGraph of a (members, B, mc, T) shape is built once."""
         key = (n_members, B, mc, T, seq)

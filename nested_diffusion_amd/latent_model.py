@@ -1,0 +1,107 @@
+"""Drop-in mirror of the reference's diffusion/latent_model.py for arch == 'linear':
+ConditionalLinear and ConditionalModel with the reference's parameter names (so
+`load_state_dict(state['noise_estimator'])` of a reference checkpoint works unchanged) and a
+forward() that runs in libnd_hip.so.  Inference only: eval mode, no autograd.
+
+The other encoders of the reference file (NewClassifier, SimNet, FashionCNN, ResNetEncoder, LeNet,
+LeNet5; latent_model.py:50-90, 216-368) are never instantiated by the shipped configs
+(configs/*.yml:18 `arch: linear`) and are out of scope.
+"""
+from __future__ import annotations
+
+import weakref
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .engine import EnsembleEngine
+
+
+class ConditionalLinear(nn.Module):
+    """latent_model.py:93-105: parameter container (lin: Linear, embed: Embedding(n_steps, num_out))."""
+
+    def __init__(self, num_in, num_out, n_steps):
+        super().__init__()
+        self.num_out = num_out
+        self.lin = nn.Linear(num_in, num_out)
+        self.embed = nn.Embedding(n_steps, num_out)
+        self.embed.weight.data.uniform_()
+
+    def forward(self, x, t):
+        raise _lib.NdError("ConditionalLinear runs fused inside ConditionalModel.forward (libnd_hip.so)")
+
+
+class ConditionalModel(nn.Module):
+    """latent_model.py:108-184 with arch 'linear'.  `config` needs .diffusion.timesteps,
+    .model.{data_dim, arch, feature_dim, hidden_dim}, .data.{num_classes, dataset}."""
+
+    def __init__(self, config, guidance=False, max_batch: int = 128, max_rows: Optional[int] = None):
+        super().__init__()
+        n_steps = config.diffusion.timesteps + 1
+        data_dim = config.model.data_dim
+        y_dim = config.data.num_classes
+        arch = config.model.arch
+        feature_dim = config.model.feature_dim
+        hidden_dim = config.model.hidden_dim
+        if arch != "linear":
+            raise NotImplementedError(f"arch '{arch}': only 'linear' (the shipped configs) is on the hot path")
+        if not guidance:
+            raise NotImplementedError("guidance=False: the shipped configs set include_guidance: True")
+        self.guidance = guidance
+        self.dims = (y_dim, data_dim, hidden_dim, feature_dim, config.diffusion.timesteps)
+        self.max_batch, self.max_rows = max_batch, max_rows or max_batch
+        self.encoder_x = nn.Sequential(
+            nn.Linear(data_dim, hidden_dim), nn.BatchNorm1d(hidden_dim), nn.Softplus(),
+            nn.Linear(hidden_dim, hidden_dim), nn.BatchNorm1d(hidden_dim), nn.Softplus(),
+            nn.Linear(hidden_dim, feature_dim))
+        self.norm = nn.BatchNorm1d(feature_dim)
+        self.lin1 = ConditionalLinear(y_dim * 2, feature_dim, n_steps)
+        self.unetnorm1 = nn.BatchNorm1d(feature_dim)
+        self.lin2 = ConditionalLinear(feature_dim, feature_dim, n_steps)
+        self.unetnorm2 = nn.BatchNorm1d(feature_dim)
+        self.lin3 = ConditionalLinear(feature_dim, feature_dim, n_steps)
+        self.unetnorm3 = nn.BatchNorm1d(feature_dim)
+        self.lin4 = nn.Linear(feature_dim, y_dim)
+        self._engine: Optional[EnsembleEngine] = None
+        self._engine_sig = None
+        self._enc_sig = None
+
+    # -- HIP engine, rebuilt when the parameters move or change --------------------------------
+    def _signature(self):
+        return tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
+
+    def hip_engine(self) -> EnsembleEngine:
+        if self.training:
+            raise _lib.NdError("ConditionalModel is inference-only here: call .eval() (BatchNorm uses running stats)")
+        dev = next(self.parameters()).device
+        if dev.type != "cuda":
+            raise _lib.NdError("ConditionalModel.forward needs the parameters on the GPU (.to('cuda')); no CPU fallback")
+        sig = self._signature()
+        if self._engine is None or self._engine_sig != sig:
+            C, D, H, F, T = self.dims
+            if self._engine is None or self._engine.device != dev:
+                self._engine = EnsembleEngine(C, D, H, F, T, n_members=1, max_batch=self.max_batch, max_rows=self.max_rows,
+                                              device=dev)
+            self._engine.load_member(0, self.state_dict())
+            self._engine_sig, self._enc_sig = sig, None
+        return self._engine
+
+    def encode(self, x: torch.Tensor) -> None:
+        """xe = norm(encoder_x(x)) (latent_model.py:170-171), cached per input tensor."""
+        eng = self.hip_engine()
+        sig = (x.data_ptr(), x._version, tuple(x.shape), str(x.device))
+        if self._enc_sig != sig:
+            eng.encode(x)
+            self._enc_sig = sig
+
+    def forward(self, x, y, t, yhat=None):
+        """eps_theta(x, y_t, t, yhat) -> [B, C] (latent_model.py:169-184)."""
+        if yhat is None:
+            raise ValueError("guidance=True requires yhat")
+        t = torch.as_tensor(t).reshape(-1)
+        if t.numel() > 1 and not bool((t == t[0]).all()):
+            raise NotImplementedError("per-row timesteps: the inference path always passes one t (diffusion_utils.py:68)")
+        self.encode(x)
+        return self.hip_engine().eps_theta(0, y, yhat, int(t[0]))

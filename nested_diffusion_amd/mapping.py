@@ -1,0 +1,149 @@
+"""Mapping network: ViT prefix blocks + mapping MLPs -> latent conditions (guiding predictions).
+
+Mirrors Diffusion.compute_guiding_prediction (classification_train_separately.py:330-348),
+mapping/models/mlp.py::Classifier and the timm 0.4.12 vit_base_patch16_224 pieces it calls
+(patch_embed, pos_drop, blocks[j], full forward).  All arithmetic runs in libnd_hip.so.
+
+Difference from the reference that does not change results: member i's prefix blocks[0..i-1] reuse
+member i-1's tokens instead of recomputing from patch_embed (15 -> 5 block evaluations; eval-mode
+blocks are deterministic functions of their input).
+"""
+from __future__ import annotations
+
+import os
+import sys
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from . import ops
+
+LN_EPS = 1e-6  # timm 0.4.12: norm_layer = partial(nn.LayerNorm, eps=1e-6)
+
+
+class Classifier:
+    """mapping/models/mlp.py:4-29.  forward: reshape(-1, in_features) -> 3x (Linear, ReLU) -> Linear.
+    (dropout is declared by the reference but never applied in forward.)"""
+
+    KEYS = [f"linear{i}.{s}" for i in range(1, 5) for s in ("weight", "bias")]
+
+    def __init__(self, state_dict: Dict[str, torch.Tensor], device="cuda"):
+        missing = [k for k in self.KEYS if k not in state_dict]
+        if missing:
+            raise KeyError(f"Classifier state_dict is missing {missing}")
+        self.device = torch.device(device)
+        self.p = {k: state_dict[k].detach().to(self.device, torch.float32).contiguous() for k in self.KEYS}
+        self.in_features = self.p["linear1.weight"].shape[1]
+
+    def state_dict(self):
+        return dict(self.p)
+
+    def __call__(self, x: torch.Tensor, dataset: str = "any") -> torch.Tensor:
+        return self.forward(x, dataset)
+
+    def forward(self, x: torch.Tensor, dataset: str = "any") -> torch.Tensor:
+        x = x.reshape(-1, self.in_features)
+        p = self.p
+        x = ops.linear(x, p["linear1.weight"], p["linear1.bias"], act="relu")
+        x = ops.linear(x, p["linear2.weight"], p["linear2.bias"], act="relu")
+        x = ops.linear(x, p["linear3.weight"], p["linear3.bias"], act="relu")
+        return ops.linear(x, p["linear4.weight"], p["linear4.bias"])
+
+
+class VisionTransformer:
+    """The subset of timm 0.4.12 VisionTransformer the path touches, over a timm state_dict."""
+
+    def __init__(self, state_dict: Dict[str, torch.Tensor], num_heads: int = 12, device="cuda"):
+        self.device = torch.device(device)
+        self.p = {k: v.detach().to(self.device, torch.float32).contiguous() for k, v in state_dict.items()
+                  if torch.is_tensor(v) and v.is_floating_point()}
+        w = self.p["patch_embed.proj.weight"]
+        self.embed_dim, self.in_chans, self.patch = w.shape[0], w.shape[1], w.shape[-1]
+        self.pe_w = w.reshape(self.embed_dim, -1).contiguous()
+        self.num_heads = num_heads
+        self.depth = 1 + max(int(k.split(".")[1]) for k in self.p if k.startswith("blocks."))
+        if self.embed_dim // num_heads != 64:
+            raise ValueError("head dim must be 64 (vit_base_patch16_224: 768 / 12)")
+
+    def patch_embed(self, x: torch.Tensor) -> torch.Tensor:
+        """PatchEmbed.forward -> tokens [B*N, embed]; pos_drop is the identity in eval."""
+        cols = ops.patchify(x, self.patch)
+        return ops.gemm_bias_act(cols, self.pe_w, self.p["patch_embed.proj.bias"])
+
+    def block(self, i: int, tok: torch.Tensor, B: int) -> torch.Tensor:
+        """Block.forward on tokens [B*N, embed]."""
+        p, pre = self.p, f"blocks.{i}."
+        N = tok.shape[0] // B
+        h = ops.layernorm(tok, p[pre + "norm1.weight"], p[pre + "norm1.bias"], LN_EPS)
+        qkv = ops.gemm_bias_act(h, p[pre + "attn.qkv.weight"], p[pre + "attn.qkv.bias"])
+        a = ops.attention(qkv, B, N, self.num_heads)
+        tok = ops.gemm_bias_act(a, p[pre + "attn.proj.weight"], p[pre + "attn.proj.bias"], residual=tok)
+        h = ops.layernorm(tok, p[pre + "norm2.weight"], p[pre + "norm2.bias"], LN_EPS)
+        h = ops.gemm_bias_act(h, p[pre + "mlp.fc1.weight"], p[pre + "mlp.fc1.bias"], act="gelu")
+        return ops.gemm_bias_act(h, p[pre + "mlp.fc2.weight"], p[pre + "mlp.fc2.bias"], residual=tok)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """Full VisionTransformer.forward (cls token + pos_embed, all blocks, norm, head on cls).
+        Only feeds the never-sampled last element of compute_guiding_prediction."""
+        B = x.shape[0]
+        tok = self.patch_embed(x).reshape(B, -1, self.embed_dim)
+        tok = torch.cat((self.p["cls_token"].expand(B, -1, -1), tok), dim=1) + self.p["pos_embed"]
+        N = tok.shape[1]
+        tok = tok.reshape(B * N, self.embed_dim).contiguous()
+        for i in range(self.depth):
+            tok = self.block(i, tok, B)
+        cls = tok.reshape(B, N, self.embed_dim)[:, 0].contiguous()
+        cls = ops.layernorm(cls, self.p["norm.weight"], self.p["norm.bias"], LN_EPS)
+        return ops.linear(cls, self.p["head.weight"], self.p["head.bias"])
+
+    __call__ = forward
+
+
+class GuidingConditioner:
+    """cond_pred_model {'vit', 'mlps'} of the reference runner (classification_train_separately.py:249-275)."""
+
+    def __init__(self, vit: VisionTransformer, mlps: Sequence[Classifier]):
+        self.vit, self.mlps = vit, list(mlps)
+
+    def compute_guiding_prediction(self, x: torch.Tensor, include_full_vit: bool = True) -> List[torch.Tensor]:
+        """classification_train_separately.py:330-348: list of K (+1) logits [B, C]."""
+        B = x.shape[0]
+        out: List[torch.Tensor] = []
+        tok = self.vit.patch_embed(x)
+        for i in range(1, len(self.mlps) + 1):
+            tok = self.vit.block(i - 1, tok, B)       # prefix shared across members
+            out.append(self.mlps[i - 1](tok))
+        if include_full_vit:
+            out.append(self.vit.forward(x))
+        return out
+
+
+# ---- checkpoint readers (SURVEY section 5 'checkpoint / resume') -----------------------------------
+def _to_state_dict(obj) -> Dict[str, torch.Tensor]:
+    if isinstance(obj, dict):
+        return obj.get("state_dict", obj)
+    if hasattr(obj, "state_dict"):
+        return obj.state_dict()
+    raise TypeError(f"cannot extract a state_dict from {type(obj)}")
+
+
+def load_pickled(path: str) -> Dict[str, torch.Tensor]:
+    """Whole-module pickles as the reference writes them (mapping/train_transformer.py:166,
+    mapping/train_mapping.py:160) or plain state_dicts.  torch >= 2.6 needs weights_only=False for
+    module pickles; the classes must be importable (timm; mlp.py next to the checkpoints)."""
+    try:
+        obj = torch.load(path, map_location="cpu", weights_only=True)
+    except Exception:
+        obj = torch.load(path, map_location="cpu", weights_only=False)
+    return _to_state_dict(obj)
+
+
+def load_conditioner(trained_path: str, dataset: str, device="cuda", num_heads: int = 12) -> GuidingConditioner:
+    """classification_train_separately.py:252-275: <path>/vit_base_patch16_224_<Dataset>.pth and every
+    file of sorted(os.listdir(<path>/MLPs))."""
+    if trained_path not in sys.path:
+        sys.path.append(trained_path)                      # so the pickled `mlp.Classifier` resolves (:255)
+    vit_sd = load_pickled(os.path.join(trained_path, f"vit_base_patch16_224_{dataset}.pth"))
+    mlp_dir = os.path.join(trained_path, "MLPs")
+    mlps = [Classifier(load_pickled(os.path.join(mlp_dir, f)), device) for f in sorted(os.listdir(mlp_dir))]
+    return GuidingConditioner(VisionTransformer(vit_sd, num_heads, device), mlps)

@@ -1,0 +1,133 @@
+"""Thin torch-tensor wrappers over the standalone operators of libnd_hip.so.
+Every function launches HIP kernels on torch's current stream; inputs must live on the GPU."""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import ND_ACT_GELU, ND_ACT_NONE, ND_ACT_RELU, ND_ACT_SOFTPLUS, check, ptr
+
+ACT = {"none": ND_ACT_NONE, None: ND_ACT_NONE, "softplus": ND_ACT_SOFTPLUS, "relu": ND_ACT_RELU, "gelu": ND_ACT_GELU}
+
+
+def _f32(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise _lib.NdError(f"{name} must be a GPU tensor (no CPU fallback)")
+    if t.dtype != torch.float32:
+        raise _lib.NdError(f"{name} must be float32")
+    return t.contiguous()
+
+
+def _stream(t: torch.Tensor):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+_ws_cache = {}
+
+
+def _workspace(nbytes: int, device) -> torch.Tensor:
+    key = (str(device),)
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = ws
+    return ws
+
+
+def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, act=None,
+           scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """act(scale * (x @ weight.T) + bias) for small row counts (weight streamed once).
+    nn.Linear + ReLU of mapping/models/mlp.py:25-28."""
+    lib = _lib.load()
+    x, weight = _f32(x, "x"), _f32(weight, "weight")
+    M, K = x.shape
+    N = weight.shape[0]
+    if weight.shape[1] != K:
+        raise ValueError(f"weight is {tuple(weight.shape)}, x is {tuple(x.shape)}")
+    bias = _f32(bias, "bias") if bias is not None else None
+    scale = _f32(scale, "scale") if scale is not None else None
+    out = torch.empty(M, N, dtype=torch.float32, device=x.device)
+    nbytes = lib.nd_linear_workspace_bytes(M, K, N)
+    ws = _workspace(nbytes, x.device)
+    check(lib.nd_linear(ptr(x), ptr(weight), ptr(scale), ptr(bias), ptr(out), M, K, N, ACT[act], ptr(ws), ws.numel(),
+                        _stream(x)), "nd_linear")
+    return out
+
+
+def gemm_bias_act(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, act=None,
+                  residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """act(x @ weight.T + bias) + residual for large row counts (ViT token matrices)."""
+    lib = _lib.load()
+    x, weight = _f32(x, "x"), _f32(weight, "weight")
+    M, K = x.shape
+    N = weight.shape[0]
+    if weight.shape[1] != K:
+        raise ValueError(f"weight is {tuple(weight.shape)}, x is {tuple(x.shape)}")
+    bias = _f32(bias, "bias") if bias is not None else None
+    residual = _f32(residual, "residual") if residual is not None else None
+    if residual is not None and tuple(residual.shape) != (M, N):
+        raise ValueError("residual must be [M, N]")
+    out = torch.empty(M, N, dtype=torch.float32, device=x.device)
+    check(lib.nd_gemm_bias_act(ptr(x), ptr(weight), ptr(bias), ptr(residual), ptr(out), M, K, N, ACT[act], _stream(x)),
+          "nd_gemm_bias_act")
+    return out
+
+
+def layernorm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float) -> torch.Tensor:
+    lib = _lib.load()
+    x = _f32(x, "x")
+    dim = x.shape[-1]
+    rows = x.numel() // dim
+    out = torch.empty_like(x)
+    check(lib.nd_layernorm(ptr(x), ptr(_f32(weight, "weight")), ptr(_f32(bias, "bias")), ptr(out), rows, dim, float(eps),
+                           _stream(x)), "nd_layernorm")
+    return out
+
+
+def attention(qkv: torch.Tensor, B: int, N: int, heads: int) -> torch.Tensor:
+    """qkv: [B*N, 3*heads*64] (output of the qkv Linear) -> [B*N, heads*64]."""
+    lib = _lib.load()
+    qkv = _f32(qkv, "qkv")
+    d = qkv.shape[-1] // (3 * heads)
+    if qkv.numel() != B * N * 3 * heads * d:
+        raise ValueError("qkv has the wrong number of elements")
+    out = torch.empty(B * N, heads * d, dtype=torch.float32, device=qkv.device)
+    check(lib.nd_attention(ptr(qkv), ptr(out), B, N, heads, d, _stream(qkv)), "nd_attention")
+    return out
+
+
+def patchify(img: torch.Tensor, p: int) -> torch.Tensor:
+    """[B, Cin, H, W] -> [B*(H/p)*(W/p), Cin*p*p] (im2col for Conv2d(k=p, s=p))."""
+    lib = _lib.load()
+    img = _f32(img, "img")
+    B, Cin, H, W = img.shape
+    out = torch.empty(B * (H // p) * (W // p), Cin * p * p, dtype=torch.float32, device=img.device)
+    check(lib.nd_patchify(ptr(img), ptr(out), B, Cin, H, W, p, _stream(img)), "nd_patchify")
+    return out
+
+
+def softmax_rows(x: torch.Tensor) -> torch.Tensor:
+    lib = _lib.load()
+    x = _f32(x, "x")
+    C = x.shape[-1]
+    out = torch.empty_like(x)
+    check(lib.nd_softmax_rows(ptr(x), ptr(out), x.numel() // C, C, _stream(x)), "nd_softmax_rows")
+    return out
+
+
+def aggregate(samples: torch.Tensor, temperature: float, return_probs: bool = False
+              ) -> Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]:
+    """samples [S, B, C] -> (prob [B, C], vote [B] int64, per-sample probs [S, B, C] or None).
+    convert_to_prob + compute_ensemble_confidence + majority_voting_for_mc_samples
+    (classification_train_separately.py:392-398, 425-447, 51-68)."""
+    lib = _lib.load()
+    samples = _f32(samples, "samples")
+    S, B, C = samples.shape
+    prob = torch.empty(B, C, dtype=torch.float32, device=samples.device)
+    vote = torch.empty(B, dtype=torch.int64, device=samples.device)
+    probs = torch.empty_like(samples) if return_probs else None
+    check(lib.nd_aggregate(ptr(samples), ptr(prob), ptr(vote), ptr(probs), S, B, C, float(temperature), _stream(samples)),
+          "nd_aggregate")
+    return prob, vote, probs

@@ -1,0 +1,189 @@
+"""Mirror of the reference runner's inference path: class Diffusion of
+diffusion/classification_train_separately.py -- __init__ schedule block (:215-226), conditioner
+loading (:249-275), compute_guiding_prediction (:330-348), convert_to_prob (:392-398),
+compute_ensemble_confidence (:425-447), majority_voting_for_mc_samples (:51-68) and the hot loop
+of test_atk (:749-794).  Training, calibration and the reporting metrics are out of scope.
+
+Host code is PyTorch plumbing; every tensor operation of the hot path runs in libnd_hip.so.
+"""
+from __future__ import annotations
+
+import logging
+import os
+import time
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from . import ops
+from .diffusion_utils import make_beta_schedule
+from .engine import EnsembleEngine
+from .mapping import GuidingConditioner, load_conditioner
+from . import dist as nd_dist
+
+CHEST = ['ChestXRay', 'ChestXRayAtkFGSM', 'ChestXRayAtkPGD', 'ChestXRayAtkBIM', 'ChestXRayAtkAUTOPGD', 'ChestXRayAtkCW',
+         'ChestXRayValidate']
+ISIC = ['ISICSkinCancer', 'ISICSkinCancerAtkFGSM', 'ISICSkinCancerAtkPGD', 'ISICSkinCancerAtkBIM',
+        'ISICSkinCancerAtkAUTOPGD', 'ISICSkinCancerAtkCW', 'ISICSkinCancerValidate']
+
+
+def majority_voting_for_mc_samples(predictions: Sequence[torch.Tensor]) -> torch.Tensor:
+    """classification_train_separately.py:51-68 -- mode over samples of argmax(raw y_0); ties -> smallest label."""
+    samples = torch.stack([p if p.is_cuda else p.cuda() for p in predictions]).float()
+    _, vote, _ = ops.aggregate(samples, 1.0)
+    return vote.to(predictions[0].device)
+
+
+def temperature_for(dataset: str) -> float:
+    """classification_train_separately.py:318-327."""
+    if dataset in CHEST:
+        return 0.1737
+    if dataset in ISIC:
+        return 0.3162
+    raise NotImplementedError(dataset)
+
+
+class Diffusion(object):
+    def __init__(self, args, config, device=None, conditioner: Optional[GuidingConditioner] = None,
+                 noise_estimator_states: Optional[List[Dict[str, torch.Tensor]]] = None):
+        """`conditioner` / `noise_estimator_states` let synthetic runs (no checkpoints on disk) inject
+        weights; otherwise they are read from the reference's checkpoint layout."""
+        self.args, self.config = args, config
+        self.seed = getattr(args, "seed", 0)
+        if device is None:
+            device = torch.device("cuda")
+        self.device = torch.device(device)
+        self.num_timesteps = config.diffusion.timesteps
+        self.mc_trials = int(getattr(args, "mc_trials", 20) or 20)          # hard-coded 20 at :770
+        # schedule (:215-226): same torch ops as the reference, fp32
+        betas = make_beta_schedule(schedule=config.diffusion.beta_schedule, num_timesteps=self.num_timesteps,
+                                   start=config.diffusion.beta_start, end=config.diffusion.beta_end)
+        betas = betas.float()                                    # T-float init tables: host ops in the reference's
+        alphas = 1.0 - betas                                     # order (CPU cumprod), pinned by tests/golden/schedule.npz
+        omabs = torch.sqrt(1 - alphas.cumprod(dim=0))
+        if config.diffusion.beta_schedule == "cosine":
+            omabs = omabs * 0.9999
+        self.betas = betas.to(self.device)
+        self.alphas = alphas.to(self.device)
+        self.one_minus_alphas_bar_sqrt = omabs.to(self.device)
+        self.temperature = temperature_for(config.data.dataset)
+        self.selected_block_indices = [0, 1, 2, 3, 4]                       # :275
+        if conditioner is None:
+            if config.diffusion.aux_cls.arch != "sevit":
+                raise NotImplementedError("only aux_cls.arch == 'sevit' is on the hot path")
+            ds = "ChestXRay" if config.data.dataset in CHEST else "ISICSkinCancer"
+            conditioner = load_conditioner(config.diffusion.trained_aux_cls_ckpt_path, ds, self.device)
+        self.cond_pred_model = conditioner
+        self.num_noise_estimators_required = len(conditioner.mlps) + 1      # :274 (the +1 is never sampled, Q1)
+        self._states = noise_estimator_states
+        self.engine: Optional[EnsembleEngine] = None
+        self.members: List[int] = []
+
+    # ---- conditioner -------------------------------------------------------------------------
+    def compute_guiding_prediction(self, x, include_full_vit: bool = True):
+        """:330-348."""
+        return self.cond_pred_model.compute_guiding_prediction(x, include_full_vit)
+
+    # ---- aggregation --------------------------------------------------------------------------
+    def convert_to_prob(self, logits: torch.Tensor) -> torch.Tensor:
+        """:392-398 -- softmax(-(y-1)^2 / T)."""
+        dev = logits.device
+        x = logits.float().to(self.device).reshape(1, -1, logits.shape[-1]).contiguous()
+        _, _, probs = ops.aggregate(x, self.temperature, return_probs=True)
+        return probs.reshape(logits.shape).to(dev)
+
+    def compute_ensemble_confidence(self, outputs: List[torch.Tensor]) -> torch.Tensor:
+        """:425-447 -- replaces every list entry by its probabilities (quirk Q4) and returns the mean."""
+        dev = outputs[0].device
+        samples = torch.stack([o.to(self.device) for o in outputs]).float().contiguous()
+        prob, _, probs = ops.aggregate(samples, self.temperature, return_probs=True)
+        for i in range(len(outputs)):
+            outputs[i] = probs[i].to(dev)
+        return prob.to(dev)
+
+    # ---- noise estimators ---------------------------------------------------------------------
+    def load_noise_estimators(self, max_batch: int, mc_trials: Optional[int] = None) -> None:
+        """:684-697.  Members actually sampled are selected_block_indices ∩ available checkpoints
+        (the reference asks for len(mlps)+1 paths and dies on the 6th, quirk Q1)."""
+        cfg = self.config
+        mc = mc_trials or self.mc_trials
+        if self._states is None:
+            paths = cfg.diffusion.trained_diffusion_ckpt_path[0]
+            states = []
+            for i in range(min(len(paths), self.num_noise_estimators_required)):
+                state = torch.load(paths[i], map_location="cpu", weights_only=False)
+                states.append(state["noise_estimator"])
+                logging.info("Diffusion model %d loaded", i)
+            self._states = states
+        self.members = [i for i in self.selected_block_indices if i < len(self._states)]
+        K = len(self.members)
+        self.engine = EnsembleEngine(cfg.data.num_classes, cfg.model.data_dim, cfg.model.hidden_dim, cfg.model.feature_dim,
+                                     self.num_timesteps, n_members=K, max_batch=max_batch, max_rows=max_batch * mc,
+                                     device=self.device)
+        for slot, i in enumerate(self.members):
+            self.engine.load_member(slot, self._states[i])
+        self.engine.set_schedule(self.alphas, self.one_minus_alphas_bar_sqrt)
+        self._states = None            # device copies live in the engine
+
+    # ---- the hot path (:749-794) --------------------------------------------------------------
+    @torch.no_grad()
+    def predict_batch(self, images_224: torch.Tensor, noise: Optional[torch.Tensor] = None, mc_trials: Optional[int] = None):
+        """images [B,3,224,224] on the GPU -> dict(samples [K*mc, B, C] raw y_0 member-major then trial,
+        vote [B], prob [B, C], probs [K*mc, B, C]).  noise: optional [K, T, B*mc, C] in reference draw order
+        (row = trial*B + image)."""
+        if self.engine is None:
+            raise RuntimeError("call load_noise_estimators() first")
+        mc = mc_trials or self.mc_trials
+        eng, K, T = self.engine, len(self.members), self.num_timesteps
+        B = images_224.shape[0]
+        C = self.config.data.num_classes
+        images_224_flat = torch.flatten(images_224, 1)                                  # :747
+        logits = self.compute_guiding_prediction(images_224, include_full_vit=False)    # :753 (6th never sampled)
+        yhat = torch.stack([ops.softmax_rows(logits[i]) for i in self.members])         # :755-758, [K,B,C]
+        eng.encode(images_224_flat)
+        if noise is None:
+            noise = torch.randn(K, T, B * mc, C, device=self.device)
+        y0 = eng.sample(yhat, yhat, noise, mc=mc, T=T)                                  # :767-777 (y_T_mean = yhat, Q2)
+        samples = y0.reshape(K * mc, B, C)                                              # member-major, then trial
+        prob, vote, probs = ops.aggregate(samples, self.temperature, return_probs=True)  # :786, :789
+        return {"samples": samples, "vote": vote, "prob": prob, "probs": probs, "yhat": yhat}
+
+    # ---- test loop ----------------------------------------------------------------------------
+    def test_atk(self, test_loader=None):
+        """:631-840 reduced to the hot path + accuracy.  Input perturbations / attacks (:726-739) and the
+        PIW / ECE / variance report (:810-838) are the 'next' rows of SURVEY 8f and raise if requested."""
+        args, config = self.args, self.config
+        for flag, off in (("noise_perturbation", 0.0), ("low_resolution", 0), ("brightness", 0.0), ("crop", 0.0)):
+            v = getattr(args, flag, off) or off
+            if (flag == "low_resolution" and v > 1) or (flag != "low_resolution" and v != off):
+                raise NotImplementedError(f"--{flag}: input perturbations are not part of the accelerated path yet")
+        if getattr(args, "contrast", 1.0) not in (1.0, None):
+            raise NotImplementedError("--contrast: input perturbations are not part of the accelerated path yet")
+        if getattr(args, "attack_name", None) not in (None, "None"):
+            raise NotImplementedError("adversarial attacks need gradients through the ViT: out of scope")
+        if test_loader is None:
+            from .data import get_test_loader
+            test_loader = get_test_loader(args, config)
+        rank, world = nd_dist.rank_world()
+        B = config.testing.batch_size
+        lo, hi = nd_dist.shard_bounds(B, rank, world)
+        self.load_noise_estimators(max_batch=max(hi - lo, 1))
+        mv_class, target_class, prob_mc = [], [], []
+        n_step_img, t0 = 0, time.time()
+        for images_raw, target in test_loader:
+            images = images_raw[lo:hi].to(self.device, torch.float32)
+            out = self.predict_batch(images)
+            prob = nd_dist.all_gather_rows(out["prob"], B, world)            # single RCCL all-gather of the logits
+            vote = nd_dist.all_gather_rows(out["vote"], B, world)
+            mv_class.append(vote.cpu()); target_class.append(target.cpu()); prob_mc.append(prob.cpu())
+            n_step_img += B * len(self.members) * self.mc_trials * self.num_timesteps
+        torch.cuda.synchronize(self.device)
+        dt = time.time() - t0
+        pred, tgt = torch.cat(mv_class), torch.cat(target_class)
+        acc = (pred == tgt).float().mean()
+        if rank == 0:
+            print(f"Majority voting accuracy for MC: {acc:.4f}")
+            logging.info("Majority voting accuracy for MC: %.4f \n", acc)
+            logging.info("throughput: %.1f denoising-step*images/s over %d GPU(s)", n_step_img / max(dt, 1e-9), world)
+        self.last_probs = torch.cat(prob_mc)
+        return acc

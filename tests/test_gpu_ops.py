@@ -1,0 +1,129 @@
+"""Standalone HIP operators (through the C ABI) against plain torch fp32 on the CPU."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import ref_cpu
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _close(got, ref, tol):
+    got, ref = got.detach().cpu().double(), ref.detach().cpu().double()
+    err = (got - ref).abs().max().item()
+    assert err <= tol * max(1.0, ref.abs().max().item()), err
+
+
+@pytest.mark.parametrize("M,K,N,act", [(1, 64, 16, None), (3, 128, 2, None), (32, 4096, 4096, "softplus"),
+                                       (32, 2048, 128, "relu"), (17, 160, 100, "relu"), (70, 256, 48, None),
+                                       (5, 16, 7, "gelu")])
+def test_linear_fused_skinny(M, K, N, act):
+    from nested_diffusion_amd import ops
+    g = torch.Generator().manual_seed(M * 1000 + N)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    s = torch.rand(N, generator=g) + 0.5
+    out = ops.linear(x.cuda(), w.cuda(), b.cuda(), act=act, scale=s.cuda())
+    ref = s * (x.double() @ w.double().T).float() + b
+    ref = {None: lambda v: v, "softplus": F.softplus, "relu": F.relu, "gelu": F.gelu}[act](ref)
+    _close(out, ref, 2e-5)
+    out2 = ops.linear(x.cuda(), w.cuda(), None, act=None)                 # no scale / shift
+    _close(out2, (x.double() @ w.double().T).float(), 2e-5)
+
+
+@pytest.mark.parametrize("M,K,N", [(4, 16384, 64), (32, 150528, 256), (2, 32768 + 16, 130), (33, 20000 - 16 * 2, 128)])
+def test_linear_splitk(M, K, N):
+    from nested_diffusion_amd import ops
+    g = torch.Generator().manual_seed(K + N)
+    x = torch.rand(M, K, generator=g)
+    w = (torch.rand(N, K, generator=g) * 2 - 1) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    out = ops.linear(x.cuda(), w.cuda(), b.cuda(), act="relu")
+    ref = F.relu((x.double() @ w.double().T).float() + b)
+    _close(out, ref, 2e-5)
+
+
+@pytest.mark.parametrize("M,K,N,act,res", [(6272, 768, 768, None, True), (392, 768, 2304, None, False),
+                                           (200, 64, 256, "gelu", False), (130, 48, 70, None, True), (1, 16, 1, "relu", False)])
+def test_gemm_bias_act(M, K, N, act, res):
+    from nested_diffusion_amd import ops
+    g = torch.Generator().manual_seed(M + N)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    r = torch.randn(M, N, generator=g) if res else None
+    out = ops.gemm_bias_act(x.cuda(), w.cuda(), b.cuda(), act=act, residual=r.cuda() if res else None)
+    ref = (x.double() @ w.double().T).float() + b
+    ref = {None: lambda v: v, "relu": F.relu, "gelu": F.gelu}[act](ref)
+    if res:
+        ref = ref + r
+    _close(out, ref, 2e-5)
+
+
+@pytest.mark.parametrize("rows,dim", [(5, 768), (197 * 3, 768), (7, 64), (3, 1024), (2, 2048)])
+def test_layernorm(rows, dim):
+    from nested_diffusion_amd import ops
+    g = torch.Generator().manual_seed(rows)
+    x = torch.randn(rows, dim, generator=g) * 3 + 1
+    w, b = torch.randn(dim, generator=g), torch.randn(dim, generator=g)
+    out = ops.layernorm(x.cuda(), w.cuda(), b.cuda(), 1e-6)
+    _close(out, F.layer_norm(x, (dim,), w, b, 1e-6), 1e-5)
+
+
+@pytest.mark.parametrize("B,N,heads", [(2, 196, 12), (1, 197, 12), (3, 16, 2), (2, 5, 1), (1, 256, 3), (2, 50, 4)])
+def test_attention(B, N, heads):
+    from nested_diffusion_amd import ops
+    d = 64
+    g = torch.Generator().manual_seed(N)
+    qkv = torch.randn(B * N, 3 * heads * d, generator=g)
+    out = ops.attention(qkv.cuda(), B, N, heads)
+    t = qkv.reshape(B, N, 3, heads, d).permute(2, 0, 3, 1, 4)
+    q, k, v = t[0], t[1], t[2]
+    a = ((q @ k.transpose(-2, -1)) * d ** -0.5).softmax(-1)
+    ref = (a @ v).transpose(1, 2).reshape(B * N, heads * d)
+    _close(out, ref, 1e-5)
+
+
+def test_patchify_matches_conv2d():
+    from nested_diffusion_amd import ops
+    g = torch.Generator().manual_seed(0)
+    img = torch.rand(2, 3, 64, 48, generator=g)
+    w = torch.randn(32, 3, 16, 16, generator=g) / 28
+    b = torch.randn(32, generator=g)
+    cols = ops.patchify(img.cuda(), 16)
+    out = ops.gemm_bias_act(cols, w.reshape(32, -1).cuda(), b.cuda())
+    ref = F.conv2d(img, w, b, stride=16).flatten(2).transpose(1, 2).reshape(-1, 32)
+    _close(out, ref, 1e-5)
+
+
+def test_softmax_and_aggregate_vs_golden():
+    from nested_diffusion_amd import ops
+    z = np.load(os.path.join(G, "aggregation.npz"))
+    for name in ("a0", "a1", "a2"):
+        temp = float(z[name + "_temp"])
+        s = torch.from_numpy(z[name + "_samples"])
+        prob, vote, probs = ops.aggregate(s.cuda(), temp, return_probs=True)
+        assert np.array_equal(vote.cpu().numpy(), z[name + "_vote"])          # integer result: exact
+        assert np.abs(prob.cpu().numpy() - z[name + "_prob"]).max() < 2e-6
+        assert np.abs(probs.cpu().numpy() - z[name + "_mutated"]).max() < 2e-6
+    x = torch.randn(37, 2)
+    _close(ops.softmax_rows(x.cuda()), torch.softmax(x, 1), 1e-6)
+    x3 = torch.randn(5, 3) * 10
+    _close(ops.softmax_rows(x3.cuda()), torch.softmax(x3, 1), 1e-6)
+
+
+def test_ops_reject_cpu_tensors_and_bad_shapes():
+    from nested_diffusion_amd import _lib, ops
+    with pytest.raises(_lib.NdError):
+        ops.linear(torch.zeros(2, 16), torch.zeros(4, 16).cuda())              # CPU tensor: no fallback
+    with pytest.raises(_lib.NdError):
+        ops.linear(torch.zeros(2, 24).cuda(), torch.zeros(4, 24).cuda())       # K not a multiple of 16
+    with pytest.raises(_lib.NdError):
+        ops.attention(torch.zeros(4, 3 * 32).cuda(), 1, 4, 1)                  # head dim 32
+    with pytest.raises(ValueError):
+        ops.linear(torch.zeros(2, 16).cuda(), torch.zeros(4, 32).cuda())

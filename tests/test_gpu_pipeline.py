@@ -1,0 +1,140 @@
+"""End-to-end parity on the GPU: conditioner, the nn.Module / p_sample_loop drop-ins, the runner's hot
+path and the config-dim golden, all through the C ABI, against the CPU oracle / reference goldens."""
+import argparse
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_cpu
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def ns(**kw):
+    return argparse.Namespace(**kw)
+
+
+def small_config(D, H, Fd, C, T, B, dataset="ChestXRay"):
+    return ns(data=ns(dataset=dataset, num_classes=C), model=ns(data_dim=D, hidden_dim=H, feature_dim=Fd, arch="linear"),
+              diffusion=ns(timesteps=T, beta_schedule="linear", beta_start=1e-4, beta_end=0.02, aux_cls=ns(arch="sevit"),
+                           trained_aux_cls_ckpt_path="", trained_diffusion_ckpt_path=[[]], include_guidance=True),
+              testing=ns(batch_size=B))
+
+
+def test_conditioner_vs_oracle_small_vit():
+    """ViT prefix (timm 0.4.12 semantics; parity unpinned upstream) + mapping MLPs."""
+    from nested_diffusion_amd.mapping import Classifier, GuidingConditioner, VisionTransformer
+    embed, heads, depth, img, patch, K, B = 128, 2, 6, 64, 16, 5, 3
+    vp = ref_cpu.init_vit_params(embed=embed, depth=depth, patch=patch, img=img, seed=5)
+    n_tok = (img // patch) ** 2
+    mlps = [ref_cpu.init_classifier_params(n_tok * embed, widths=(256, 128, 64), seed=10 + i) for i in range(K)]
+    x = torch.rand(B, 3, img, img, generator=torch.Generator().manual_seed(1))
+    ref = ref_cpu.compute_guiding_prediction(vp, mlps, x, heads, depth, full_vit=True, share_prefix=False)
+    cond = GuidingConditioner(VisionTransformer(vp, heads), [Classifier(m) for m in mlps])
+    got = cond.compute_guiding_prediction(x.cuda(), include_full_vit=True)
+    assert len(got) == K + 1
+    for k in range(K + 1):
+        err = (got[k].cpu() - ref[k]).abs().max().item()
+        assert err < 2e-5 * max(1.0, ref[k].abs().max().item()), (k, err)
+
+
+def test_module_and_p_sample_loop_dropin():
+    """ConditionalModel.load_state_dict(reference state) + p_sample_loop / p_sample / p_sample_t_1to0 with
+    the reference's signatures reproduce the golden trajectory."""
+    from nested_diffusion_amd import diffusion_utils as du
+    from nested_diffusion_amd.latent_model import ConditionalModel
+    z = np.load(os.path.join(G, "sampler_s0.npz"))
+    p = {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("p.")}
+    D, H, Fd, C, T, B, seed = [int(v) for v in z["dims"]]
+    model = ConditionalModel(small_config(D, H, Fd, C, T, B), guidance=True, max_batch=8)
+    model.load_state_dict(p, strict=True)
+    model = model.to("cuda").eval()
+    x, yhat, noise = (torch.from_numpy(z[k]).cuda() for k in ("x", "yhat", "noise"))
+    alphas, omabs = torch.from_numpy(z["alphas"]).cuda(), torch.from_numpy(z["omabs"]).cuda()
+    seq = du.p_sample_loop(model, x, yhat, yhat, T, alphas, omabs, only_last_sample=False, noise=noise)
+    assert isinstance(seq, list) and len(seq) == T + 1
+    ref = z["seq"]
+    got = torch.stack(seq).cpu().numpy()
+    assert np.abs(got - ref).max() < 2e-5 * max(1.0, np.abs(ref).max())
+    y0 = du.p_sample_loop(model, x, yhat, yhat, T, alphas, omabs, only_last_sample=True, noise=noise)
+    assert np.array_equal(y0.cpu().numpy(), got[-1])
+    # forward() == eps_theta of the reference at t = T-1 on y_T
+    eps = model(x, torch.from_numpy(ref[0]).cuda(), torch.tensor([T - 1]), yhat)
+    i = list(z["eps_ts"]).index(T - 1)
+    assert np.abs(eps.cpu().numpy() - z["eps"][i]).max() < 5e-5 * max(1.0, np.abs(z["eps"][i]).max())
+    # single reverse steps: y_T -> y_{T-1} with the golden draw, and the last step y_1 -> y_0
+    y1 = du.p_sample(model, x, torch.from_numpy(ref[0]).cuda(), yhat, yhat, T - 1, alphas, omabs, z=noise[1])
+    assert np.abs(y1.cpu().numpy() - ref[1]).max() < 2e-5 * max(1.0, np.abs(ref[1]).max())
+    yl = du.p_sample_t_1to0(model, x, torch.from_numpy(ref[T - 1]).cuda(), yhat, yhat, omabs)
+    assert np.abs(yl.cpu().numpy() - ref[T]).max() < 2e-5 * max(1.0, np.abs(ref[T]).max())
+    # without supplied noise it still runs (device RNG) and returns the right shapes
+    y_rand = du.p_sample_loop(model, x, yhat, yhat, T, alphas, omabs, only_last_sample=True)
+    assert tuple(y_rand.shape) == (B, C) and torch.isfinite(y_rand).all()
+    with pytest.raises(Exception):
+        model.train()(x, yhat, torch.tensor([0]), yhat)        # inference only
+
+
+def test_runner_hot_path_vs_oracle():
+    """Diffusion.predict_batch (test_atk :749-794) == oracle ensemble on identical weights and noise:
+    class probabilities within 1e-3 (the north-star criterion), votes equal."""
+    from nested_diffusion_amd.mapping import Classifier, GuidingConditioner, VisionTransformer
+    from nested_diffusion_amd.runner import Diffusion
+    embed, heads, depth, img, patch, K, B, T, mc, C = 128, 2, 5, 32, 16, 5, 6, 20, 3, 2
+    D, H, Fd = 3 * img * img, 128, 128
+    vp = ref_cpu.init_vit_params(embed=embed, depth=depth, patch=patch, img=img, seed=3)
+    n_tok = (img // patch) ** 2
+    mlps = [ref_cpu.init_classifier_params(n_tok * embed, widths=(128, 64, 32), seed=20 + i) for i in range(K)]
+    members = [ref_cpu.init_cond_model_params(D, H, Fd, C, T, True, seed=40 + i) for i in range(K)]
+    cfg = small_config(D, H, Fd, C, T, B)
+    cond = GuidingConditioner(VisionTransformer(vp, heads), [Classifier(m) for m in mlps])
+    runner = Diffusion(ns(seed=1, mc_trials=mc), cfg, device="cuda", conditioner=cond, noise_estimator_states=members)
+    runner.load_noise_estimators(max_batch=B)
+    g = torch.Generator().manual_seed(9)
+    x = torch.rand(B, 3, img, img, generator=g)
+    noise = torch.randn(K, mc, T, B, C, generator=g)                      # oracle layout [K, mc, T, B, C]
+    out = runner.predict_batch(x.cuda(), noise=noise.permute(0, 2, 1, 3, 4).reshape(K, T, mc * B, C).cuda())
+    # oracle: as-written conditioner (no prefix sharing), as-written sampler
+    logits = ref_cpu.compute_guiding_prediction(vp, mlps, x, heads, depth, full_vit=False, share_prefix=False)
+    yhat = [torch.softmax(l, dim=1) for l in logits]
+    alphas, omabs = ref_cpu.schedule_tables("linear", T, 1e-4, 0.02)
+    assert torch.equal(runner.alphas.cpu(), alphas) and torch.equal(runner.one_minus_alphas_bar_sqrt.cpu(), omabs)
+    raw, vote, prob = ref_cpu.ensemble_predict(members, x.flatten(1), yhat, T, alphas, omabs, noise, runner.temperature, hoist=False)
+    got = out["samples"].cpu()
+    ref = torch.stack(raw)
+    assert got.shape == ref.shape == (K * mc, B, C)
+    assert (got - ref).abs().max() < 1e-4 * max(1.0, ref.abs().max())
+    assert (out["prob"].cpu() - prob).abs().max() < 1e-3
+    assert torch.equal(out["vote"].cpu(), vote)
+    # reference-API aggregation helpers
+    lst = [r.clone() for r in raw]
+    p2 = runner.compute_ensemble_confidence(lst)
+    assert (p2 - prob).abs().max() < 1e-5 and (lst[0] - ref_cpu.convert_to_prob(raw[0], runner.temperature)).abs().max() < 1e-5
+    assert (runner.convert_to_prob(raw[1]) - ref_cpu.convert_to_prob(raw[1], runner.temperature)).abs().max() < 1e-5
+
+
+def test_config_dims_vs_reference_golden():
+    """D=150528, F=H=4096 (configs/chest_x_ray.yml dims), T=10, B=4: trajectory produced by the REFERENCE on CPU."""
+    from nested_diffusion_amd import synthetic
+    from nested_diffusion_amd.engine import EnsembleEngine
+    z = np.load(os.path.join(G, "sampler_full.npz"))
+    D, H, Fd, C, T, B, seed = [int(v) for v in z["dims"]]
+    p = ref_cpu.init_cond_model_params(D, H, Fd, C, T, True, seed=seed)       # same seeded weights as the fixture
+    x = torch.rand(B, D, generator=torch.Generator().manual_seed(int(z["x_seed"])))
+    eng = EnsembleEngine(C, D, H, Fd, T, n_members=1, max_batch=B)
+    eng.load_member(0, p)
+    del p
+    alphas, omabs = ref_cpu.schedule_tables("linear", T, 1e-4, 0.02)
+    eng.set_schedule(alphas, omabs)
+    eng.encode(x)
+    xe = eng.member_buffer(0, 0, B).cpu().numpy()
+    assert np.abs(xe - z["xe"]).max() < 2e-5 * max(1.0, np.abs(z["xe"]).max())
+    yhat, noise = torch.from_numpy(z["yhat"]).cuda(), torch.from_numpy(z["noise"]).cuda()
+    seq = eng.sample(yhat[None], yhat[None], noise[None], return_seq=True)[0].cpu().numpy()
+    ref = z["seq"]
+    assert np.abs(seq - ref).max() < 1e-4 * max(1.0, np.abs(ref).max()), np.abs(seq - ref).max()
+    pr = ref_cpu.convert_to_prob(torch.from_numpy(seq[-1]), 0.1737)
+    pr_ref = ref_cpu.convert_to_prob(torch.from_numpy(ref[-1]), 0.1737)
+    assert (pr - pr_ref).abs().max() < 1e-3
