@@ -125,6 +125,14 @@ int nd_sample(nd_handle h, int member0, int n_members, const float *yhat_dev, co
               const float *noise_dev, float *y0_out_dev, float *seq_out_dev, int B, int mc, int T,
               int use_graph, void *stream);
 
+/* Kernel-duration probes for the roofline report: when enabled, up to 8 denoising steps of every
+ * nd_sample graph (or eager loop) get hipEvent record nodes around their three kernels on the launch
+ * stream.  nd_profile_read (after the stream is synchronised) returns the mean duration in
+ * microseconds of the last nd_sample's probed launches: out_us[0] step head, [1] lin2 block,
+ * [2] lin3+lin4 block; *n_samples = probed steps. */
+int nd_set_profiling(nd_handle h, int enable);
+int nd_profile_read(nd_handle h, float *out_us, int *n_samples);
+
 /* Device address of an internal per-member buffer (tests/profiling): which = 0 xe [B,F],
  * 1 h1 [M,F], 2 h2 [M,F]. */
 int nd_member_buffer(nd_handle h, int member, int which, void **out_dev);

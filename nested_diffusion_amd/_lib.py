@@ -63,6 +63,8 @@ SIGNATURES = {
     "nd_eps_theta": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i, _i, _vp]),
     "nd_p_sample": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _vp]),
     "nd_sample": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "nd_set_profiling": (_i, [_vp, _i]),
+    "nd_profile_read": (_i, [_vp, C.POINTER(C.c_float), C.POINTER(_i)]),
     "nd_member_buffer": (_i, [_vp, _i, _i, C.POINTER(_vp)]),
     "nd_memcpy_d2d": (_i, [_vp, _vp, _sz, _vp]),
     "nd_linear_workspace_bytes": (_sz, [_i, _i, _i]),
@@ -92,6 +94,13 @@ def load() -> C.CDLL:
             f"{LIB_PATH} is missing: the MI355X HIP library has not been built "
             "(run `python -m nested_diffusion_amd.build` or __graft_entry__.build()). "
             "There is no CPU fallback on the product path.")
+    # torch bundles its own libamdhip64.so.7; libnd_hip.so NEEDs the same soname.  Import torch first so
+    # both share ONE HIP runtime (device pointers and streams are exchanged between them); loading the
+    # system runtime first would leave two runtimes in the process.
+    import torch  # noqa: F401
+    torch_hip = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+    if os.path.exists(torch_hip):
+        C.CDLL(torch_hip, mode=C.RTLD_GLOBAL)
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)       # AttributeError if the header and the library disagree

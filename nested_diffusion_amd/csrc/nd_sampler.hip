@@ -263,6 +263,9 @@ struct nd_handle_s {
     bool enc_splitk = false;
     std::map<GraphKey, hipGraphExec_t> graphs;
     int encoded_B = -1;
+    bool profiling = false;
+    std::vector<hipEvent_t> probe_events;   // 4 per probed step: e0 | head | e1 | lin2 | e2 | lin3 | e3
+    int probe_steps = 0;
 };
 
 static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -515,6 +518,28 @@ extern "C" int nd_member_buffer(nd_handle h, int k, int which, void** out) {
     return ND_OK;
 }
 
+extern "C" int nd_set_profiling(nd_handle h, int enable) {
+    if (!h) return nd_set_err(ND_ERR_ARG, "handle is NULL");
+    if (h->profiling != (enable != 0)) drop_graphs(h);
+    h->profiling = enable != 0;
+    return ND_OK;
+}
+
+extern "C" int nd_profile_read(nd_handle h, float* out_us, int* n_samples) {
+    if (!h || !out_us || !n_samples) return nd_set_err(ND_ERR_ARG, "NULL argument");
+    double acc[3] = {0, 0, 0};
+    const int n = h->probe_steps;
+    for (int s = 0; s < n; ++s)
+        for (int k = 0; k < 3; ++k) {
+            float ms = 0.f;
+            HIP_CHECK(hipEventElapsedTime(&ms, h->probe_events[4 * s + k], h->probe_events[4 * s + k + 1]));
+            acc[k] += ms * 1000.0;
+        }
+    for (int k = 0; k < 3; ++k) out_us[k] = n ? (float)(acc[k] / n) : 0.f;
+    *n_samples = n;
+    return ND_OK;
+}
+
 extern "C" int nd_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream) {
     if (!dst || !src) return nd_set_err(ND_ERR_ARG, "NULL pointer");
     HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
@@ -582,6 +607,16 @@ struct Emitter {
     hipGraph_t graph = nullptr;
     hipGraphNode_t last = nullptr;
     hipError_t err = hipSuccess;
+    void record(hipEvent_t ev) {
+        if (err != hipSuccess) return;
+        if (!graph) {
+            err = hipEventRecord(ev, st);
+        } else {
+            hipGraphNode_t node;
+            err = hipGraphAddEventRecordNode(&node, graph, last ? &last : nullptr, last ? 1 : 0, ev);
+            last = node;
+        }
+    }
     void emit(void* fn, dim3 grid, dim3 block, void** args) {
         if (err != hipSuccess) return;
         if (!graph) {
@@ -606,15 +641,32 @@ static hipError_t emit_loop(nd_handle_s* h, Emitter& em, int m0, int nm, StepIO 
     const dim3 ghead((F + 1023) / 1024, M, nm), gsk = skinny_grid(F, M, nm);
     void* f2 = skinny_fn<0>(M);
     void* f3 = skinny_fn<1>(M);
+    // probes: up to 8 steps spread over the loop (never step 0: its head is the cheap INIT form)
+    const int want = h->profiling ? (T - 1 < 8 ? T - 1 : 8) : 0;
+    const int stride = want > 0 ? (T - 1) / want : 0;
+    if ((int)h->probe_events.size() < 4 * want) {
+        const size_t old = h->probe_events.size();
+        h->probe_events.resize(4 * want);
+        for (size_t e = old; e < h->probe_events.size(); ++e)
+            if (hipEventCreate(&h->probe_events[e]) != hipSuccess) return hipErrorOutOfMemory;
+    }
+    int probed = 0;
     for (int i = 0; i < T; ++i) {
         int t = T - 1 - i, t_prev = t + 1, mode = (i == 0) ? ND_HEAD_INIT : ND_HEAD_UPDATE, istep = i;
+        const bool probe = want > 0 && i >= 1 && probed < want && ((i - 1) % stride) == stride / 2;
+        hipEvent_t* ev = probe ? &h->probe_events[4 * probed] : nullptr;
+        if (probe) em.record(ev[0]);
         void* ah[] = {&mdev, &io, &mode, &istep, &t_prev, &t, &B, &M, &maxM, &C, &F, &NT, &Tn};
         em.emit((void*)k_step_head, ghead, dim3(256), ah);
+        if (probe) em.record(ev[1]);
         void* a2[] = {&d0, &t2, &M, &t};
         em.emit(f2, gsk, dim3(256), a2);
+        if (probe) em.record(ev[2]);
         void* a3[] = {&d0, &t3, &M, &t};
         em.emit(f3, gsk, dim3(256), a3);
+        if (probe) { em.record(ev[3]); ++probed; }
     }
+    h->probe_steps = probed;
     int eps_only = 0, par_cur = (T - 1) & 1;
     float* eps_out = nullptr;
     size_t eps_ms = 0;

@@ -133,6 +133,17 @@ class EnsembleEngine:
                                    self._stream()), "nd_p_sample")
         return out
 
+    def set_profiling(self, enable: bool) -> None:
+        check(self.lib.nd_set_profiling(self.h, 1 if enable else 0), "nd_set_profiling")
+
+    def profile_read(self):
+        """(head_us, lin2_us, lin3_us, n_probed_steps) of the last sample(); synchronises the stream."""
+        torch.cuda.current_stream(self.device).synchronize()
+        us = (C.c_float * 3)()
+        n = C.c_int(0)
+        check(self.lib.nd_profile_read(self.h, us, C.byref(n)), "nd_profile_read")
+        return float(us[0]), float(us[1]), float(us[2]), int(n.value)
+
     def static_buffers(self, n_members: int, B: int, mc: int, T: int, seq: bool) -> Dict[str, torch.Tensor]:
         """Fixed-address I/O tensors so the hipGraph of a (members, B, mc, T) shape is built once."""
         key = (n_members, B, mc, T, seq)
