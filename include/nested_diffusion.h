@@ -84,8 +84,8 @@ size_t nd_workspace_bytes(const nd_config *cfg);
 int nd_bind_workspace(nd_handle h, void *workspace_dev, size_t bytes);
 
 /* Replaces ConditionalModel(...).load_state_dict(state['noise_estimator']) + .eval() + .to(device)
- * (classification_train_separately.py:685-697, 773).  Keeps the raw weight pointers (the caller
- * must keep them alive) and folds eval-mode BatchNorm1d, the Linear bias and the per-timestep
+ * (classification_train_separately.py:685-697, 773).  Repacks the five weight matrices into the
+ * workspace in fragment order (the caller may free its tensors when the call returns) and folds eval-mode BatchNorm1d, the Linear bias and the per-timestep
  * Embedding gain into scale/shift tables:  BN(g_t * (W h + b)) = a_t * (W h) + c_t. */
 int nd_load_member(nd_handle h, int member, const nd_member_weights *w, void *stream);
 
@@ -133,18 +133,23 @@ int nd_sample(nd_handle h, int member0, int n_members, const float *yhat_dev, co
 int nd_set_profiling(nd_handle h, int enable);
 int nd_profile_read(nd_handle h, float *out_us, int *n_samples);
 
-/* Device address of an internal per-member buffer (tests/profiling): which = 0 xe [B,F],
- * 1 h1 [M,F], 2 h2 [M,F]. */
-int nd_member_buffer(nd_handle h, int member, int which, void **out_dev);
-/* hipMemcpyAsync(device -> device) on `stream`; lets a host without HIP bindings read such a buffer. */
-int nd_memcpy_d2d(void *dst_dev, const void *src_dev, size_t bytes, void *stream);
+/* Copy of an internal per-member activation (tests / debugging), converted from the packed layout to
+ * row-major: which = 0 xe [rows<=B, F], 1 h1 [rows<=M, F], 2 h2 [rows<=M, F] -> dst_dev [rows, F]. */
+int nd_member_buffer(nd_handle h, int member, int which, float *dst_dev, int rows, void *stream);
 
 /* ---- standalone operators (mapping network + unit tests) ---------------------------------- */
+/* "frag16" packing of a K-contiguous matrix [R, K] (K % 16 == 0) into the MFMA fragment order the
+ * weight-streaming kernels read with fully coalesced 1 KiB wave loads (layout: DESIGN.md).  Rows are
+ * padded to a multiple of 16 with zeros.  Weights are packed once (mapping-MLP load time). */
+size_t nd_packed_bytes(int R, int K);
+int nd_pack_rows(const float *src_dev, float *dst_packed_dev, int R, int K, void *stream);
+
 /* out[M,N] = act(scale[n] * (x[M,K] . W[N,K]^T) + shift[n]); scale/shift may be NULL (1 / 0).
- * nn.Linear + bias (+ReLU) of mapping/models/mlp.py:25-28 with shift = bias; skinny-M weight
- * streaming, split-K across workgroups when K is large.  workspace_dev: >= nd_linear_workspace_bytes. */
+ * nn.Linear + bias (+ReLU) of mapping/models/mlp.py:25-28 with shift = bias.  x and out are row-major,
+ * w_packed_dev is the nd_pack_rows image of the [N, K] nn.Linear weight.  Skinny-M weight streaming;
+ * split-K across workgroups when K is large.  workspace_dev: >= nd_linear_workspace_bytes(M, K, N). */
 size_t nd_linear_workspace_bytes(int M, int K, int N);
-int nd_linear(const float *x_dev, const float *w_dev, const float *scale_dev, const float *shift_dev,
+int nd_linear(const float *x_dev, const float *w_packed_dev, const float *scale_dev, const float *shift_dev,
               float *out_dev, int M, int K, int N, int act, void *workspace_dev, size_t workspace_bytes,
               void *stream);
 

@@ -11,40 +11,60 @@ int nd_set_err(int code, const char* fmt, ...);
             return nd_set_err(ND_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
     } while (0)
 
-// ---- nd_linear: mapping/models/mlp.py:25-28 ---------------------------------------------------
-extern "C" size_t nd_linear_workspace_bytes(int M, int K, int N) {
-    if (M < 1 || K < 16 || N < 1) return 0;
-    if (!nd_use_splitk(K)) return 256;
-    return (size_t)nd_pick_splitk(K, N) * M * N * sizeof(float) + 256;
+// ---- packing ---------------------------------------------------------------------------------
+extern "C" size_t nd_packed_bytes(int R, int K) {
+    if (R < 1 || K < 16 || (K % 16)) return 0;
+    return nd_packed_floats(R, K) * sizeof(float);
 }
 
-extern "C" int nd_linear(const float* x, const float* w, const float* scale, const float* shift, float* out, int M, int K, int N,
+extern "C" int nd_pack_rows(const float* src, float* dst, int R, int K, void* stream) {
+    if (!src || !dst) return nd_set_err(ND_ERR_ARG, "NULL tensor");
+    if (R < 1 || K < 16 || (K % 16)) return nd_set_err(ND_ERR_ARG, "need R >= 1 and K a positive multiple of 16 (K=%d)", K);
+    const size_t n4 = nd_packed_floats(R, K) / 4, want = (n4 + 255) / 256;
+    hipLaunchKernelGGL(k_pack_rows, dim3((unsigned)(want > 8192 ? 8192 : want)), dim3(256), 0, (hipStream_t)stream, src, dst, R, K);
+    HIP_CHECK(hipGetLastError());
+    return ND_OK;
+}
+
+// ---- nd_linear: mapping/models/mlp.py:25-28 ---------------------------------------------------
+extern "C" size_t nd_linear_workspace_bytes(int M, int K, int N) {
+    if (M < 1 || K < 16 || (K % 16) || N < 1) return 0;
+    size_t fl = nd_packed_floats(M, K) + 64;
+    if (nd_use_splitk(K)) fl += nd_splitk_part_floats(M, K, N);
+    return fl * sizeof(float) + 256;
+}
+
+extern "C" int nd_linear(const float* x, const float* wpk, const float* scale, const float* shift, float* out, int M, int K, int N,
                          int act, void* ws, size_t ws_bytes, void* stream) {
-    if (!x || !w || !out) return nd_set_err(ND_ERR_ARG, "NULL tensor");
+    if (!x || !wpk || !out) return nd_set_err(ND_ERR_ARG, "NULL tensor");
     if (M < 1 || N < 1 || K < 16 || (K % 16)) return nd_set_err(ND_ERR_ARG, "need M,N >= 1 and K a positive multiple of 16 (K=%d)", K);
     if (act < 0 || act > 3) return nd_set_err(ND_ERR_ARG, "unknown activation %d", act);
+    const size_t need = nd_linear_workspace_bytes(M, K, N);
+    if (!ws || ws_bytes < need) return nd_set_err(ND_ERR_ARG, "workspace too small: %zu < %zu", ws_bytes, need);
     hipStream_t st = (hipStream_t)stream;
+    float* xpk = (float*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+    float* part = xpk + nd_packed_floats(M, K) + 64;
+    int rc = nd_pack_rows(x, xpk, M, K, stream);
+    if (rc != ND_OK) return rc;
     if (nd_use_splitk(K)) {
-        const size_t need = nd_linear_workspace_bytes(M, K, N);
-        if (!ws || ws_bytes < need) return nd_set_err(ND_ERR_ARG, "workspace too small: %zu < %zu", ws_bytes, need);
         const int S = nd_pick_splitk(K, N), nch = K / 16;
-        SplitKDesc sd{x, w, (float*)ws, K, N, S, (nch + S - 1) / S};
+        SplitKDesc sd{xpk, wpk, part, K, N, S, (nch + S - 1) / S};
         const int ntiles = (N + ND_SPK_TILE_N - 1) / ND_SPK_TILE_N;
-        const int mt = M <= 16 ? 1 : (M <= 32 ? 2 : 4);
-        dim3 grid(ntiles * S, (M + 16 * mt - 1) / (16 * mt), 1);
-        if (mt == 1) hipLaunchKernelGGL((k_skinny_splitk<1>), grid, dim3(256), 0, st, sd, (const SplitKDesc*)nullptr, M);
-        else if (mt == 2) hipLaunchKernelGGL((k_skinny_splitk<2>), grid, dim3(256), 0, st, sd, (const SplitKDesc*)nullptr, M);
-        else hipLaunchKernelGGL((k_skinny_splitk<4>), grid, dim3(256), 0, st, sd, (const SplitKDesc*)nullptr, M);
-        SplitKEpiDesc se{(const float*)ws, scale, shift, out, N, S, act};
-        const size_t tot = (size_t)M * N;
-        hipLaunchKernelGGL(k_splitk_epilogue, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, se, (const SplitKEpiDesc*)nullptr, M);
-    } else {
-        SkinnyDesc d{x, w, scale, shift, out, nullptr, nullptr, K, N, 0, act};
         const int mt = nd_pick_mt(M);
-        dim3 grid((N + 15) / 16, (M + 16 * mt - 1) / (16 * mt), 1);
-        if (mt == 1) hipLaunchKernelGGL((k_skinny_fused<1, 4, 0>), grid, dim3(256), 0, st, d, (const SkinnyDesc*)nullptr, M, 0);
-        else if (mt == 2) hipLaunchKernelGGL((k_skinny_fused<2, 4, 0>), grid, dim3(256), 0, st, d, (const SkinnyDesc*)nullptr, M, 0);
-        else hipLaunchKernelGGL((k_skinny_fused<4, 4, 0>), grid, dim3(256), 0, st, d, (const SkinnyDesc*)nullptr, M, 0);
+        dim3 grid(ntiles * S, (M + 16 * mt - 1) / (16 * mt), 1);
+        if (mt == 1) hipLaunchKernelGGL((k_skinny_splitk<1, true>), grid, dim3(256), 0, st, sd, (const SplitKDesc*)nullptr, M);
+        else if (mt == 2) hipLaunchKernelGGL((k_skinny_splitk<2, true>), grid, dim3(256), 0, st, sd, (const SplitKDesc*)nullptr, M);
+        else hipLaunchKernelGGL((k_skinny_splitk<4, true>), grid, dim3(256), 0, st, sd, (const SplitKDesc*)nullptr, M);
+        SplitKEpiDesc se{part, scale, shift, out, N, S, act, 0};
+        const size_t q = (size_t)(((M + 15) / 16) * 16) * (((N + 15) / 16) * 16) / 4;
+        hipLaunchKernelGGL(k_splitk_epilogue, dim3((unsigned)((q + 255) / 256)), dim3(256), 0, st, se, (const SplitKEpiDesc*)nullptr, M);
+    } else {
+        SkinnyDesc d{xpk, wpk, scale, shift, out, nullptr, nullptr, K, N, 0, act, 0};
+        const SkinnyDesc* table = nullptr;
+        int t = 0;
+        const SkinnyLaunch L = nd_skinny_launch<0>(K, N, M, 1);
+        void* args[] = {&d, &table, &M, &t};
+        HIP_CHECK(hipLaunchKernel(L.fn, L.grid, L.block, args, 0, st));
     }
     HIP_CHECK(hipGetLastError());
     return ND_OK;

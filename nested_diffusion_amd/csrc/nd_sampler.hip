@@ -42,14 +42,14 @@ int nd_set_err(int code, const char* fmt, ...) {
 // device-side member record (everything the head / final kernels need)
 // ---------------------------------------------------------------------------------------------
 struct MemberDev {
-    const float* lin1_w;   // [F, 2C]
+    const float* lin1_w;   // [F, 2C] (workspace copy)
     const float* lin4_b;   // [C]
     const float* A1;       // [T, F] folded gain  (unetnorm1 scale * embed1[t])
     const float* C1;       // [T, F] folded shift
-    const float* xe;       // [B, F]
-    float* h1;             // [M, F]
+    const float* xe;       // frag16 [B, F]
+    float* h1;             // frag16 [M, F]
     float* ybuf;           // [2, maxM, C]
-    const float* epart;    // [NT, M, C]
+    const float* epart;    // [M, C, NT]
 };
 
 struct StepIO {             // per-launch tensors with a member-major leading stride
@@ -95,7 +95,8 @@ __device__ __forceinline__ float nd_reduce_eps(const float* __restrict__ epart, 
                                                float* red /* [NT_THREADS/64] */) {
     const int tid = threadIdx.x;
     float s = 0.f;
-    for (int tl = tid; tl < NT; tl += NT_THREADS) s += epart[((size_t)tl * M + m) * C + c];
+    const float* row = epart + ((size_t)m * C + c) * NT;
+    for (int tl = tid; tl < NT; tl += NT_THREADS) s += row[tl];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
     __syncthreads();
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(256) void k_step_head(const MemberDev* __restrict__
     __syncthreads();
     const int n = blockIdx.x * 1024 + tid * 4;
     if (n >= F) return;
-    const int C2 = 2 * C;
+    const int C2 = 2 * C, nchF = F >> 4;
     float u[4] = {0.f, 0.f, 0.f, 0.f};
     for (int q = 0; q < C2; ++q) {
         const float yq = ysh[q];
@@ -160,13 +161,13 @@ __global__ __launch_bounds__(256) void k_step_head(const MemberDev* __restrict__
     }
     const float4 a = *reinterpret_cast<const float4*>(mb.A1 + (size_t)t * F + n);
     const float4 cc = *reinterpret_cast<const float4*>(mb.C1 + (size_t)t * F + n);
-    const float4 xe = *reinterpret_cast<const float4*>(mb.xe + (size_t)b * F + n);
+    const float4 xe = *reinterpret_cast<const float4*>(mb.xe + nd_pk(b, n, nchF));
     float4 h;
     h.x = nd_softplus(a.x * u[0] + cc.x) * xe.x;
     h.y = nd_softplus(a.y * u[1] + cc.y) * xe.y;
     h.z = nd_softplus(a.z * u[2] + cc.z) * xe.z;
     h.w = nd_softplus(a.w * u[3] + cc.w) * xe.w;
-    *reinterpret_cast<float4*>(mb.h1 + (size_t)m * F + n) = h;
+    *reinterpret_cast<float4*>(mb.h1 + nd_pk(m, n, nchF)) = h;
 }
 
 // Last step (t = 0): y_0 = y_0_reparam (diffusion_utils.py:96-111), or plain eps output for the
@@ -229,13 +230,14 @@ __global__ void k_fold_steps(float* A, float* Cc, const float* emb, const float*
 // ---------------------------------------------------------------------------------------------
 // host handle
 // ---------------------------------------------------------------------------------------------
-enum { L_ENC1 = 0, L_ENC2 = 1, L_LIN2 = 2, L_LIN3 = 3, L_COUNT = 4 };
+enum { L_ENC0 = 0, L_ENC1 = 1, L_ENC2 = 2, L_LIN2 = 3, L_LIN3 = 4, L_COUNT = 5 };
 
 struct MemberHost {
     bool loaded = false;
-    nd_member_weights w{};
     float *sc0, *sh0, *sc1, *sh1, *sc2, *sh2;
     float *A[3], *Cc[3];
+    float *w_enc0, *w_enc3, *w_enc6, *w_lin2, *w_lin3;   // frag16-packed weights
+    float *w_lin1, *w_lin4, *b_lin4;                      // small row-major copies
     float *e0, *e1, *xe, *ybuf, *h1, *h2, *epart, *splitk;
 };
 
@@ -255,9 +257,10 @@ struct nd_handle_s {
     std::vector<MemberHost> members;
     MemberDev* members_dev = nullptr;      // [K]
     SkinnyDesc* descs_dev = nullptr;       // [L_COUNT][K]
-    SplitKDesc* spk_dev = nullptr;         // [K]   encoder_x.0
+    SplitKDesc* spk_dev = nullptr;         // [K]   encoder_x.0 (split-K form)
     SplitKEpiDesc* spke_dev = nullptr;     // [K]
     float *alphas = nullptr, *omabs = nullptr;
+    float* xpack = nullptr;                // frag16 [maxB][D] image batch shared by all members
     int sched_T = 0;
     int NT = 0, S0 = 0;
     bool enc_splitk = false;
@@ -281,8 +284,9 @@ struct Carver {
 
 static void carve(nd_handle_s* h, char* base, size_t* total) {
     const nd_config& c = h->cfg;
-    const size_t K = c.n_members, H = c.hidden_dim, F = c.feature_dim, T = c.n_steps, C = c.y_dim;
+    const size_t K = c.n_members, H = c.hidden_dim, F = c.feature_dim, T = c.n_steps, C = c.y_dim, D = c.data_dim;
     const size_t mB = c.max_batch, mM = c.max_rows;
+    const size_t pB = ((mB + 15) / 16) * 16, pM = ((mM + 15) / 16) * 16;   // rows padded to whole 16-row tiles
     h->NT = (int)((F + 15) / 16);
     h->enc_splitk = nd_use_splitk(c.data_dim);
     h->S0 = h->enc_splitk ? nd_pick_splitk(c.data_dim, c.hidden_dim) : 0;
@@ -293,17 +297,21 @@ static void carve(nd_handle_s* h, char* base, size_t* total) {
     h->spke_dev = cv.take<SplitKEpiDesc>(K);
     h->alphas = cv.take<float>(T);
     h->omabs = cv.take<float>(T);
+    h->xpack = cv.take<float>(pB * D);
     for (size_t k = 0; k < K; ++k) {
         MemberHost& m = h->members[k];
         m.sc0 = cv.take<float>(H); m.sh0 = cv.take<float>(H);
         m.sc1 = cv.take<float>(H); m.sh1 = cv.take<float>(H);
         m.sc2 = cv.take<float>(F); m.sh2 = cv.take<float>(F);
         for (int l = 0; l < 3; ++l) { m.A[l] = cv.take<float>(T * F); m.Cc[l] = cv.take<float>(T * F); }
-        m.e0 = cv.take<float>(mB * H); m.e1 = cv.take<float>(mB * H); m.xe = cv.take<float>(mB * F);
+        m.w_enc0 = cv.take<float>(H * D); m.w_enc3 = cv.take<float>(H * H); m.w_enc6 = cv.take<float>(F * H);
+        m.w_lin2 = cv.take<float>(F * F); m.w_lin3 = cv.take<float>(F * F);
+        m.w_lin1 = cv.take<float>(F * 2 * C); m.w_lin4 = cv.take<float>(C * F); m.b_lin4 = cv.take<float>(C);
+        m.e0 = cv.take<float>(pB * H); m.e1 = cv.take<float>(pB * H); m.xe = cv.take<float>(pB * F);
         m.ybuf = cv.take<float>(2 * mM * C);
-        m.h1 = cv.take<float>(mM * F); m.h2 = cv.take<float>(mM * F);
+        m.h1 = cv.take<float>(pM * F); m.h2 = cv.take<float>(pM * F);
         m.epart = cv.take<float>((size_t)h->NT * mM * C);
-        m.splitk = cv.take<float>(h->enc_splitk ? (size_t)h->S0 * mB * H : 1);
+        m.splitk = cv.take<float>(h->enc_splitk ? nd_splitk_part_floats((int)mB, (int)D, (int)H) : 1);
     }
     *total = cv.off;
 }
@@ -349,6 +357,7 @@ static void drop_graphs(nd_handle_s* h) {
 extern "C" int nd_destroy(nd_handle h) {
     if (!h) return ND_OK;
     drop_graphs(h);
+    for (hipEvent_t e : h->probe_events) (void)hipEventDestroy(e);
     delete h;
     return ND_OK;
 }
@@ -362,17 +371,28 @@ extern "C" int nd_bind_workspace(nd_handle h, void* ws, size_t bytes) {
     h->ws = (char*)ws;
     h->ws_bytes = bytes;
     drop_graphs(h);
+    for (auto& m : h->members) m.loaded = false;
+    // activations: padded tile rows must hold finite values before the first kernel reads them
+    HIP_CHECK(hipMemset(h->xpack, 0, (size_t)((char*)h->members[0].sc0 - (char*)h->xpack)));
+    for (auto& m : h->members) HIP_CHECK(hipMemset(m.e0, 0, (size_t)((char*)m.splitk - (char*)m.e0)));
     return ND_OK;
 }
 
 extern "C" int nd_set_schedule(nd_handle h, const float* alphas_dev, const float* omabs_dev, int T, void* stream) {
     if (!h || !h->ws) return nd_set_err(ND_ERR_STATE, "workspace not bound");
+    if (!alphas_dev || !omabs_dev) return nd_set_err(ND_ERR_ARG, "NULL schedule");
     if (T < 1 || T > h->cfg.n_steps) return nd_set_err(ND_ERR_ARG, "T=%d outside [1,%d]", T, h->cfg.n_steps);
     hipStream_t st = (hipStream_t)stream;
     HIP_CHECK(hipMemcpyAsync(h->alphas, alphas_dev, sizeof(float) * T, hipMemcpyDeviceToDevice, st));
     HIP_CHECK(hipMemcpyAsync(h->omabs, omabs_dev, sizeof(float) * T, hipMemcpyDeviceToDevice, st));
     h->sched_T = T;
     return ND_OK;
+}
+
+static void launch_pack(const float* src, float* dst, int R, int K, hipStream_t st) {
+    const size_t n4 = (size_t)((R + 15) / 16) * 16 * K / 4;
+    const size_t want = (n4 + 255) / 256;
+    hipLaunchKernelGGL(k_pack_rows, dim3((unsigned)(want > 8192 ? 8192 : want)), dim3(256), 0, st, src, dst, R, K);
 }
 
 extern "C" int nd_load_member(nd_handle h, int k, const nd_member_weights* w, void* stream) {
@@ -386,7 +406,6 @@ extern "C" int nd_load_member(nd_handle h, int k, const nd_member_weights* w, vo
     const nd_config& c = h->cfg;
     const int H = c.hidden_dim, F = c.feature_dim, T = c.n_steps, C = c.y_dim, D = c.data_dim;
     MemberHost& m = h->members[k];
-    m.w = *w;
     auto g1 = [](int n) { return dim3((n + 255) / 256); };
     hipLaunchKernelGGL(k_fold_bn, g1(H), dim3(256), 0, st, m.sc0, m.sh0, w->enc0_b, w->bn0_w, w->bn0_b, w->bn0_mean, w->bn0_var, H);
     hipLaunchKernelGGL(k_fold_bn, g1(H), dim3(256), 0, st, m.sc1, m.sh1, w->enc3_b, w->bn1_w, w->bn1_b, w->bn1_mean, w->bn1_var, H);
@@ -401,27 +420,39 @@ extern "C" int nd_load_member(nd_handle h, int k, const nd_member_weights* w, vo
     for (int l = 0; l < 3; ++l)
         hipLaunchKernelGGL(k_fold_steps, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, m.A[l], m.Cc[l], embs[l], lb[l],
                            bw[l], bb[l], bm[l], bv[l], T, F);
+    // weights -> frag16 in the workspace; the raw tensors are not referenced after this call returns
+    launch_pack(w->enc0_w, m.w_enc0, H, D, st);
+    launch_pack(w->enc3_w, m.w_enc3, H, H, st);
+    launch_pack(w->enc6_w, m.w_enc6, F, H, st);
+    launch_pack(w->lin2_w, m.w_lin2, F, F, st);
+    launch_pack(w->lin3_w, m.w_lin3, F, F, st);
+    HIP_CHECK(hipMemcpyAsync(m.w_lin1, w->lin1_w, sizeof(float) * F * 2 * C, hipMemcpyDeviceToDevice, st));
+    HIP_CHECK(hipMemcpyAsync(m.w_lin4, w->lin4_w, sizeof(float) * C * F, hipMemcpyDeviceToDevice, st));
+    HIP_CHECK(hipMemcpyAsync(m.b_lin4, w->lin4_b, sizeof(float) * C, hipMemcpyDeviceToDevice, st));
     HIP_CHECK(hipGetLastError());
 
-    MemberDev md{w->lin1_w, w->lin4_b, m.A[0], m.Cc[0], m.xe, m.h1, m.ybuf, m.epart};
+    MemberDev md{m.w_lin1, m.b_lin4, m.A[0], m.Cc[0], m.xe, m.h1, m.ybuf, m.epart};
     SkinnyDesc ds[L_COUNT];
-    ds[L_ENC1] = SkinnyDesc{m.e0, w->enc3_w, m.sc1, m.sh1, m.e1, nullptr, nullptr, H, H, C, ND_ACT_SOFTPLUS};
-    ds[L_ENC2] = SkinnyDesc{m.e1, w->enc6_w, m.sc2, m.sh2, m.xe, nullptr, nullptr, H, F, C, ND_ACT_NONE};
-    ds[L_LIN2] = SkinnyDesc{m.h1, w->lin2_w, m.A[1], m.Cc[1], m.h2, nullptr, nullptr, F, F, C, ND_ACT_SOFTPLUS};
-    ds[L_LIN3] = SkinnyDesc{m.h2, w->lin3_w, m.A[2], m.Cc[2], nullptr, w->lin4_w, m.epart, F, F, C, ND_ACT_SOFTPLUS};
-    // small synchronous H2D copies: load time only, never on the sampling path
+    ds[L_ENC0] = SkinnyDesc{h->xpack, m.w_enc0, m.sc0, m.sh0, m.e0, nullptr, nullptr, D, H, C, ND_ACT_SOFTPLUS, 1};
+    ds[L_ENC1] = SkinnyDesc{m.e0, m.w_enc3, m.sc1, m.sh1, m.e1, nullptr, nullptr, H, H, C, ND_ACT_SOFTPLUS, 1};
+    ds[L_ENC2] = SkinnyDesc{m.e1, m.w_enc6, m.sc2, m.sh2, m.xe, nullptr, nullptr, H, F, C, ND_ACT_NONE, 1};
+    ds[L_LIN2] = SkinnyDesc{m.h1, m.w_lin2, m.A[1], m.Cc[1], m.h2, nullptr, nullptr, F, F, C, ND_ACT_SOFTPLUS, 1};
+    ds[L_LIN3] = SkinnyDesc{m.h2, m.w_lin3, m.A[2], m.Cc[2], nullptr, m.w_lin4, m.epart, F, F, C, ND_ACT_SOFTPLUS, 0};
+    // small synchronous H2D copies: load time only, never on the sampling path.  The sync also means the
+    // caller may release its raw weight tensors as soon as this function returns.
     HIP_CHECK(hipStreamSynchronize(st));
     HIP_CHECK(hipMemcpy(h->members_dev + k, &md, sizeof md, hipMemcpyHostToDevice));
     for (int l = 0; l < L_COUNT; ++l)
         HIP_CHECK(hipMemcpy(h->descs_dev + (size_t)l * c.n_members + k, &ds[l], sizeof(SkinnyDesc), hipMemcpyHostToDevice));
     if (h->enc_splitk) {
         const int nch = D / 16;
-        SplitKDesc sd{nullptr, w->enc0_w, m.splitk, D, H, h->S0, (nch + h->S0 - 1) / h->S0};
-        SplitKEpiDesc se{m.splitk, m.sc0, m.sh0, m.e0, H, h->S0, ND_ACT_SOFTPLUS};
+        SplitKDesc sd{h->xpack, m.w_enc0, m.splitk, D, H, h->S0, (nch + h->S0 - 1) / h->S0};
+        SplitKEpiDesc se{m.splitk, m.sc0, m.sh0, m.e0, H, h->S0, ND_ACT_SOFTPLUS, 1};
         HIP_CHECK(hipMemcpy(h->spk_dev + k, &sd, sizeof sd, hipMemcpyHostToDevice));
         HIP_CHECK(hipMemcpy(h->spke_dev + k, &se, sizeof se, hipMemcpyHostToDevice));
     }
     m.loaded = true;
+    drop_graphs(h);
     return ND_OK;
 }
 
@@ -434,33 +465,11 @@ static int check_range(nd_handle_s* h, int m0, int nm) {
 }
 
 template <int MODE>
-static void launch_skinny(const SkinnyDesc* table, int K_unused, int N, int M, int t, int nm, hipStream_t st) {
-    (void)K_unused;
-    const SkinnyDesc d0{};
-    const int mt = nd_pick_mt(M);
-    const dim3 block(256);
-    if (mt == 1) {
-        dim3 grid((N + 15) / 16, (M + 15) / 16, nm);
-        hipLaunchKernelGGL((k_skinny_fused<1, 4, MODE>), grid, block, 0, st, d0, table, M, t);
-    } else if (mt == 2) {
-        dim3 grid((N + 15) / 16, (M + 31) / 32, nm);
-        hipLaunchKernelGGL((k_skinny_fused<2, 4, MODE>), grid, block, 0, st, d0, table, M, t);
-    } else {
-        dim3 grid((N + 15) / 16, (M + 63) / 64, nm);
-        hipLaunchKernelGGL((k_skinny_fused<4, 4, MODE>), grid, block, 0, st, d0, table, M, t);
-    }
-}
-
-template <int MODE>
-static void* skinny_fn(int M) {
-    const int mt = nd_pick_mt(M);
-    if (mt == 1) return (void*)k_skinny_fused<1, 4, MODE>;
-    if (mt == 2) return (void*)k_skinny_fused<2, 4, MODE>;
-    return (void*)k_skinny_fused<4, 4, MODE>;
-}
-static dim3 skinny_grid(int N, int M, int nm) {
-    const int mt = nd_pick_mt(M);
-    return dim3((N + 15) / 16, (M + 16 * mt - 1) / (16 * mt), nm);
+static hipError_t launch_skinny(const SkinnyDesc* table, int K, int N, int M, int t, int nm, hipStream_t st) {
+    SkinnyDesc d0{};
+    const SkinnyLaunch L = nd_skinny_launch<MODE>(K, N, M, nm);
+    void* args[] = {&d0, &table, &M, &t};
+    return hipLaunchKernel(L.fn, L.grid, L.block, args, 0, st);
 }
 
 extern "C" int nd_encode(nd_handle h, int m0, int nm, const float* x_dev, int B, void* stream) {
@@ -471,50 +480,40 @@ extern "C" int nd_encode(nd_handle h, int m0, int nm, const float* x_dev, int B,
     hipStream_t st = (hipStream_t)stream;
     const nd_config& c = h->cfg;
     const int K = c.n_members, H = c.hidden_dim, F = c.feature_dim, D = c.data_dim;
+    launch_pack(x_dev, h->xpack, B, D, st);       // images -> frag16 once; every member reads the same batch
     if (h->enc_splitk) {
-        // every member reads the same x: patch the descriptors' x pointer via a by-value override
-        for (int k = m0; k < m0 + nm; ++k) {
-            MemberHost& m = h->members[k];
-            const int nch = D / 16;
-            SplitKDesc sd{x_dev, m.w.enc0_w, m.splitk, D, H, h->S0, (nch + h->S0 - 1) / h->S0};
-            const int ntiles = (H + ND_SPK_TILE_N - 1) / ND_SPK_TILE_N;
-            const int mt = B <= 16 ? 1 : (B <= 32 ? 2 : 4);
-            dim3 grid(ntiles * h->S0, (B + 16 * mt - 1) / (16 * mt), 1);
-            if (mt == 1) hipLaunchKernelGGL((k_skinny_splitk<1>), grid, dim3(256), 0, st, sd, (const SplitKDesc*)nullptr, B);
-            else if (mt == 2) hipLaunchKernelGGL((k_skinny_splitk<2>), grid, dim3(256), 0, st, sd, (const SplitKDesc*)nullptr, B);
-            else hipLaunchKernelGGL((k_skinny_splitk<4>), grid, dim3(256), 0, st, sd, (const SplitKDesc*)nullptr, B);
-        }
-        const size_t tot = (size_t)B * H;
-        hipLaunchKernelGGL(k_splitk_epilogue, dim3((unsigned)((tot + 255) / 256), 1, nm), dim3(256), 0, st, SplitKEpiDesc{},
+        const int ntiles = (H + ND_SPK_TILE_N - 1) / ND_SPK_TILE_N;
+        const int mt = nd_pick_mt(B);
+        dim3 grid(ntiles * h->S0, (B + 16 * mt - 1) / (16 * mt), nm);
+        const SplitKDesc* tb = h->spk_dev + m0;
+        if (mt == 1) hipLaunchKernelGGL((k_skinny_splitk<1, true>), grid, dim3(256), 0, st, SplitKDesc{}, tb, B);
+        else if (mt == 2) hipLaunchKernelGGL((k_skinny_splitk<2, true>), grid, dim3(256), 0, st, SplitKDesc{}, tb, B);
+        else hipLaunchKernelGGL((k_skinny_splitk<4, true>), grid, dim3(256), 0, st, SplitKDesc{}, tb, B);
+        const size_t q = (size_t)(((B + 15) / 16) * 16) * H / 4;
+        hipLaunchKernelGGL(k_splitk_epilogue, dim3((unsigned)((q + 255) / 256), 1, nm), dim3(256), 0, st, SplitKEpiDesc{},
                            (const SplitKEpiDesc*)(h->spke_dev + m0), B);
     } else {
-        for (int k = m0; k < m0 + nm; ++k) {
-            MemberHost& m = h->members[k];
-            SkinnyDesc d{x_dev, m.w.enc0_w, m.sc0, m.sh0, m.e0, nullptr, nullptr, D, H, c.y_dim, ND_ACT_SOFTPLUS};
-            const int mt = nd_pick_mt(B);
-            dim3 grid((H + 15) / 16, (B + 16 * mt - 1) / (16 * mt), 1);
-            if (mt == 1) hipLaunchKernelGGL((k_skinny_fused<1, 4, 0>), grid, dim3(256), 0, st, d, (const SkinnyDesc*)nullptr, B, 0);
-            else if (mt == 2) hipLaunchKernelGGL((k_skinny_fused<2, 4, 0>), grid, dim3(256), 0, st, d, (const SkinnyDesc*)nullptr, B, 0);
-            else hipLaunchKernelGGL((k_skinny_fused<4, 4, 0>), grid, dim3(256), 0, st, d, (const SkinnyDesc*)nullptr, B, 0);
-        }
+        HIP_CHECK(launch_skinny<0>(h->descs_dev + (size_t)L_ENC0 * K + m0, D, H, B, 0, nm, st));
     }
-    launch_skinny<0>(h->descs_dev + (size_t)L_ENC1 * K + m0, H, H, B, 0, nm, st);
-    launch_skinny<0>(h->descs_dev + (size_t)L_ENC2 * K + m0, H, F, B, 0, nm, st);
+    HIP_CHECK(launch_skinny<0>(h->descs_dev + (size_t)L_ENC1 * K + m0, H, H, B, 0, nm, st));
+    HIP_CHECK(launch_skinny<0>(h->descs_dev + (size_t)L_ENC2 * K + m0, H, F, B, 0, nm, st));
     HIP_CHECK(hipGetLastError());
     h->encoded_B = B;
     return ND_OK;
 }
 
-extern "C" int nd_member_buffer(nd_handle h, int k, int which, void** out) {
-    if (!h || !h->ws || !out) return nd_set_err(ND_ERR_ARG, "bad argument");
+extern "C" int nd_member_buffer(nd_handle h, int k, int which, float* dst_dev, int rows, void* stream) {
+    if (!h || !h->ws || !dst_dev) return nd_set_err(ND_ERR_ARG, "bad argument");
     if (k < 0 || k >= h->cfg.n_members) return nd_set_err(ND_ERR_ARG, "member out of range");
+    if (rows < 1 || rows > h->cfg.max_rows) return nd_set_err(ND_ERR_ARG, "rows out of range");
     MemberHost& m = h->members[k];
-    switch (which) {
-        case 0: *out = m.xe; break;
-        case 1: *out = m.h1; break;
-        case 2: *out = m.h2; break;
-        default: return nd_set_err(ND_ERR_ARG, "which=%d unknown", which);
-    }
+    const float* src = which == 0 ? m.xe : which == 1 ? m.h1 : which == 2 ? m.h2 : nullptr;
+    if (!src) return nd_set_err(ND_ERR_ARG, "which=%d unknown", which);
+    if (which == 0 && rows > h->cfg.max_batch) return nd_set_err(ND_ERR_ARG, "xe holds at most max_batch rows");
+    const int F = h->cfg.feature_dim;
+    const size_t n4 = (size_t)((rows + 15) / 16) * 16 * F / 4;
+    hipLaunchKernelGGL(k_unpack_rows, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, dst_dev, rows, F);
+    HIP_CHECK(hipGetLastError());
     return ND_OK;
 }
 
@@ -540,18 +539,26 @@ extern "C" int nd_profile_read(nd_handle h, float* out_us, int* n_samples) {
     return ND_OK;
 }
 
-extern "C" int nd_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream) {
-    if (!dst || !src) return nd_set_err(ND_ERR_ARG, "NULL pointer");
-    HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
-    return ND_OK;
-}
-
 static int check_rows(nd_handle_s* h, int B, int mc, int T) {
     if (B < 1 || B > h->cfg.max_batch) return nd_set_err(ND_ERR_ARG, "B=%d outside [1,%d]", B, h->cfg.max_batch);
     if (mc < 1 || (long)B * mc > h->cfg.max_rows) return nd_set_err(ND_ERR_ARG, "B*mc=%ld exceeds max_rows=%d", (long)B * mc, h->cfg.max_rows);
     if (T < 1 || T > h->cfg.n_steps) return nd_set_err(ND_ERR_ARG, "T=%d outside [1,%d]", T, h->cfg.n_steps);
     if (h->sched_T < T) return nd_set_err(ND_ERR_STATE, "schedule holds %d steps, need %d (nd_set_schedule)", h->sched_T, T);
     if (h->encoded_B != B) return nd_set_err(ND_ERR_STATE, "nd_encode ran with B=%d, sampling asks B=%d", h->encoded_B, B);
+    return ND_OK;
+}
+
+// head -> lin2 -> lin3 for one member, then `final` in the requested mode (1 eps, 2 p_sample, 3 1to0)
+static int single_eval(nd_handle_s* h, int member, StepIO io, int t, int final_mode, float* out, int B, int mc, hipStream_t st) {
+    const nd_config& c = h->cfg;
+    const int K = c.n_members, F = c.feature_dim, C = c.y_dim, M = B * mc;
+    hipLaunchKernelGGL(k_step_head, dim3((F + 1023) / 1024, M, 1), dim3(256), 0, st, (const MemberDev*)(h->members_dev + member), io,
+                       ND_HEAD_GIVEN, 0, 0, t, B, M, c.max_rows, C, F, h->NT, c.n_steps);
+    HIP_CHECK(launch_skinny<0>(h->descs_dev + (size_t)L_LIN2 * K + member, F, F, M, t, 1, st));
+    HIP_CHECK(launch_skinny<1>(h->descs_dev + (size_t)L_LIN3 * K + member, F, F, M, t, 1, st));
+    hipLaunchKernelGGL(k_step_final, dim3(M, 1, 1), dim3(64), 0, st, (const MemberDev*)(h->members_dev + member), io, final_mode, t, B, M,
+                       c.max_rows, C, h->NT, c.n_steps, out, (size_t)0);
+    HIP_CHECK(hipGetLastError());
     return ND_OK;
 }
 
@@ -563,19 +570,9 @@ extern "C" int nd_eps_theta(nd_handle h, int member, const float* y_dev, const f
     if (B < 1 || B > h->cfg.max_batch || mc < 1 || (long)B * mc > h->cfg.max_rows) return nd_set_err(ND_ERR_ARG, "B/mc out of range");
     if (t < 0 || t >= h->cfg.n_steps) return nd_set_err(ND_ERR_ARG, "t=%d outside [0,%d)", t, h->cfg.n_steps);
     if (h->encoded_B != B) return nd_set_err(ND_ERR_STATE, "nd_encode ran with B=%d, asked B=%d", h->encoded_B, B);
-    hipStream_t st = (hipStream_t)stream;
-    const nd_config& c = h->cfg;
-    const int K = c.n_members, F = c.feature_dim, C = c.y_dim, M = B * mc;
     StepIO io{};
     io.yhat = yhat_dev; io.y_in = y_dev; io.alphas = h->alphas; io.omabs = h->omabs;
-    hipLaunchKernelGGL(k_step_head, dim3((F + 1023) / 1024, M, 1), dim3(256), 0, st, (const MemberDev*)(h->members_dev + member), io,
-                       ND_HEAD_GIVEN, 0, 0, t, B, M, c.max_rows, C, F, h->NT, c.n_steps);
-    launch_skinny<0>(h->descs_dev + (size_t)L_LIN2 * K + member, F, F, M, t, 1, st);
-    launch_skinny<1>(h->descs_dev + (size_t)L_LIN3 * K + member, F, F, M, t, 1, st);
-    hipLaunchKernelGGL(k_step_final, dim3(M, 1, 1), dim3(64), 0, st, (const MemberDev*)(h->members_dev + member), io, 1, 0, B, M,
-                       c.max_rows, C, h->NT, c.n_steps, eps_out, (size_t)0);
-    HIP_CHECK(hipGetLastError());
-    return ND_OK;
+    return single_eval(h, member, io, t, 1, eps_out, B, mc, (hipStream_t)stream);
 }
 
 extern "C" int nd_p_sample(nd_handle h, int member, const float* y_dev, const float* yhat_dev, const float* ymean_dev,
@@ -583,22 +580,13 @@ extern "C" int nd_p_sample(nd_handle h, int member, const float* y_dev, const fl
     int rc = check_range(h, member, 1);
     if (rc != ND_OK) return rc;
     if (!y_dev || !yhat_dev || !ymean_dev || !y_out) return nd_set_err(ND_ERR_ARG, "NULL tensor");
+    if (t < 0) return nd_set_err(ND_ERR_ARG, "t must be >= 0");
     if (t > 0 && !z_dev) return nd_set_err(ND_ERR_ARG, "z_dev is required for t >= 1");
     rc = check_rows(h, B, mc, t + 1);
     if (rc != ND_OK) return rc;
-    hipStream_t st = (hipStream_t)stream;
-    const nd_config& c = h->cfg;
-    const int K = c.n_members, F = c.feature_dim, C = c.y_dim, M = B * mc;
     StepIO io{};
     io.yhat = yhat_dev; io.ymean = ymean_dev; io.y_in = y_dev; io.noise = z_dev; io.alphas = h->alphas; io.omabs = h->omabs;
-    hipLaunchKernelGGL(k_step_head, dim3((F + 1023) / 1024, M, 1), dim3(256), 0, st, (const MemberDev*)(h->members_dev + member), io,
-                       ND_HEAD_GIVEN, 0, 0, t, B, M, c.max_rows, C, F, h->NT, c.n_steps);
-    launch_skinny<0>(h->descs_dev + (size_t)L_LIN2 * K + member, F, F, M, t, 1, st);
-    launch_skinny<1>(h->descs_dev + (size_t)L_LIN3 * K + member, F, F, M, t, 1, st);
-    hipLaunchKernelGGL(k_step_final, dim3(M, 1, 1), dim3(64), 0, st, (const MemberDev*)(h->members_dev + member), io, t > 0 ? 2 : 3, t, B,
-                       M, c.max_rows, C, h->NT, c.n_steps, y_out, (size_t)0);
-    HIP_CHECK(hipGetLastError());
-    return ND_OK;
+    return single_eval(h, member, io, t, t > 0 ? 2 : 3, y_out, B, mc, (hipStream_t)stream);
 }
 
 // Enqueue (eager) or record (graph) the 3T+1 kernels of one p_sample_loop for a member range.
@@ -638,9 +626,8 @@ static hipError_t emit_loop(nd_handle_s* h, Emitter& em, int m0, int nm, StepIO 
     const SkinnyDesc* t2 = h->descs_dev + (size_t)L_LIN2 * K + m0;
     const SkinnyDesc* t3 = h->descs_dev + (size_t)L_LIN3 * K + m0;
     SkinnyDesc d0{};
-    const dim3 ghead((F + 1023) / 1024, M, nm), gsk = skinny_grid(F, M, nm);
-    void* f2 = skinny_fn<0>(M);
-    void* f3 = skinny_fn<1>(M);
+    const dim3 ghead((F + 1023) / 1024, M, nm);
+    const SkinnyLaunch L2 = nd_skinny_launch<0>(F, F, M, nm), L3 = nd_skinny_launch<1>(F, F, M, nm);
     // probes: up to 8 steps spread over the loop (never step 0: its head is the cheap INIT form)
     const int want = h->profiling ? (T - 1 < 8 ? T - 1 : 8) : 0;
     const int stride = want > 0 ? (T - 1) / want : 0;
@@ -660,10 +647,10 @@ static hipError_t emit_loop(nd_handle_s* h, Emitter& em, int m0, int nm, StepIO 
         em.emit((void*)k_step_head, ghead, dim3(256), ah);
         if (probe) em.record(ev[1]);
         void* a2[] = {&d0, &t2, &M, &t};
-        em.emit(f2, gsk, dim3(256), a2);
+        em.emit(L2.fn, L2.grid, L2.block, a2);
         if (probe) em.record(ev[2]);
         void* a3[] = {&d0, &t3, &M, &t};
-        em.emit(f3, gsk, dim3(256), a3);
+        em.emit(L3.fn, L3.grid, L3.block, a3);
         if (probe) { em.record(ev[3]); ++probed; }
     }
     h->probe_steps = probed;

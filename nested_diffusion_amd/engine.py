@@ -83,8 +83,10 @@ class EnsembleEngine:
                 raise ValueError(f"'{key}' has shape {tuple(t.shape)}, expected {want[key]}")
             held[key] = t
             setattr(w, field, t.data_ptr())
-        self._weights[k] = held            # keep the device tensors alive: the library holds raw pointers
+        # the library repacks / folds everything into its workspace and synchronises before returning,
+        # so `held` (and the caller's tensors) can be released afterwards
         check(self.lib.nd_load_member(self.h, k, C.byref(w), self._stream()), "nd_load_member")
+        del held
 
     def set_schedule(self, alphas: torch.Tensor, one_minus_alphas_bar_sqrt: torch.Tensor) -> None:
         a, s = self._dev(alphas), self._dev(one_minus_alphas_bar_sqrt)
@@ -105,10 +107,8 @@ class EnsembleEngine:
 
     def member_buffer(self, k: int, which: int, rows: int) -> torch.Tensor:
         """Copy of an internal buffer: which = 0 xe [rows,F], 1 h1, 2 h2 (tests only)."""
-        p = C.c_void_p()
-        check(self.lib.nd_member_buffer(self.h, k, which, C.byref(p)), "nd_member_buffer")
         out = torch.empty(rows, self.F, dtype=torch.float32, device=self.device)
-        check(self.lib.nd_memcpy_d2d(ptr(out), p, out.numel() * 4, self._stream()), "nd_memcpy_d2d")
+        check(self.lib.nd_member_buffer(self.h, k, which, ptr(out), rows, self._stream()), "nd_member_buffer")
         return out
 
     def eps_theta(self, member: int, y: torch.Tensor, yhat: torch.Tensor, t: int, mc: int = 1) -> torch.Tensor:

@@ -32,11 +32,12 @@ class Classifier:
         if missing:
             raise KeyError(f"Classifier state_dict is missing {missing}")
         self.device = torch.device(device)
-        self.p = {k: state_dict[k].detach().to(self.device, torch.float32).contiguous() for k in self.KEYS}
-        self.in_features = self.p["linear1.weight"].shape[1]
-
-    def state_dict(self):
-        return dict(self.p)
+        self.in_features = state_dict["linear1.weight"].shape[1]
+        self.p = {}
+        for k in self.KEYS:
+            t = state_dict[k].detach().to(self.device, torch.float32).contiguous()
+            # weights are repacked once into the streaming kernels' fragment order; the row-major copy is dropped
+            self.p[k] = ops.PackedWeight(t) if k.endswith("weight") else t
 
     def __call__(self, x: torch.Tensor, dataset: str = "any") -> torch.Tensor:
         return self.forward(x, dataset)

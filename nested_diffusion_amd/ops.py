@@ -36,22 +36,42 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
     return ws
 
 
-def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, act=None,
+class PackedWeight:
+    """An nn.Linear weight [N, K] repacked once into the fragment order the streaming kernels read."""
+
+    def __init__(self, weight: torch.Tensor):
+        lib = _lib.load()
+        weight = _f32(weight, "weight")
+        self.N, self.K = weight.shape
+        nbytes = lib.nd_packed_bytes(self.N, self.K)
+        if nbytes == 0:
+            raise _lib.NdError(f"cannot pack a [{self.N}, {self.K}] weight: K must be a positive multiple of 16")
+        self.data = torch.empty(nbytes // 4, dtype=torch.float32, device=weight.device)
+        check(lib.nd_pack_rows(ptr(weight), ptr(self.data), self.N, self.K, _stream(weight)), "nd_pack_rows")
+
+
+def linear(x: torch.Tensor, weight, bias: Optional[torch.Tensor] = None, act=None,
            scale: Optional[torch.Tensor] = None) -> torch.Tensor:
     """act(scale * (x @ weight.T) + bias) for small row counts (weight streamed once).
-    nn.Linear + ReLU of mapping/models/mlp.py:25-28."""
+    nn.Linear + ReLU of mapping/models/mlp.py:25-28.  `weight` is a PackedWeight (packed once) or a
+    plain [N, K] tensor (packed on the fly: tests / one-off calls)."""
     lib = _lib.load()
-    x, weight = _f32(x, "x"), _f32(weight, "weight")
+    x = _f32(x, "x")
     M, K = x.shape
-    N = weight.shape[0]
-    if weight.shape[1] != K:
-        raise ValueError(f"weight is {tuple(weight.shape)}, x is {tuple(x.shape)}")
+    if not isinstance(weight, PackedWeight):
+        if weight.dim() != 2 or weight.shape[1] != K:
+            raise ValueError(f"weight is {tuple(weight.shape)}, x is {tuple(x.shape)}")
+        weight = PackedWeight(weight)
+    N = weight.N
+    if weight.K != K:
+        raise ValueError(f"weight is [{weight.N}, {weight.K}], x is {tuple(x.shape)}")
+    wdata = weight.data
     bias = _f32(bias, "bias") if bias is not None else None
     scale = _f32(scale, "scale") if scale is not None else None
     out = torch.empty(M, N, dtype=torch.float32, device=x.device)
     nbytes = lib.nd_linear_workspace_bytes(M, K, N)
     ws = _workspace(nbytes, x.device)
-    check(lib.nd_linear(ptr(x), ptr(weight), ptr(scale), ptr(bias), ptr(out), M, K, N, ACT[act], ptr(ws), ws.numel(),
+    check(lib.nd_linear(ptr(x), ptr(wdata), ptr(scale), ptr(bias), ptr(out), M, K, N, ACT[act], ptr(ws), ws.numel(),
                         _stream(x)), "nd_linear")
     return out
 

@@ -1,0 +1,244 @@
+// ubench_skinny.hip -- design-space microbenchmark for the skinny-M weight-streaming GEMM
+// (the lin2 / lin3 ConditionalLinear blocks: M = 32, K = N = 4096, G members per launch).
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/ubench_skinny.hip -o tools/ubench_skinny
+// Each variant computes out[g][m][n] = sum_k x[g][m][k] * w[g][n][k] (checked against variant 0),
+// interleaved rounds in one process, median + min reported as GB/s of weight bytes.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <cmath>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+
+struct P {
+    const float* x;    // row-major [G][M][K]
+    const float* xp;   // packed     [G][M/16][K/16][64 lanes][4]
+    const float* w;    // row-major [G][N][K]
+    const float* wp;   // packed     [G][N/16][K/16][64][4]
+    float* out;        // [G][M][N]
+    int M, K, N;
+};
+
+// WPACK/XPACK: operand in MFMA fragment order (every wave load = 1 KiB contiguous)
+// NF: 16-row W fragments per wave (workgroup n-tile = 16*NF); MT: 16-row x fragments; WAVES split K.
+// U: chunks per pipeline stage.  NT: nontemporal W loads.  ILV: interleave accumulators in the MFMA order.
+template <int MT, int NF, int WAVES, int U, bool WPACK, bool XPACK, bool NT>
+__global__ __launch_bounds__(WAVES * 64) void k_var(P p) {
+    const int g = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int K = p.K, N = p.N, M = p.M;
+    const int nch = K >> 4;
+    const int ntile = blockIdx.x;  // 16*NF rows
+    const float* wbase[NF];
+    const float* xbase[MT];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+        const int nf = ntile * NF + f;  // 16-row fragment index
+        if (WPACK) wbase[f] = p.wp + ((size_t)g * (N / 16) + nf) * (size_t)nch * 256 + lane * 4;
+        else wbase[f] = p.w + ((size_t)g * N + nf * 16 + (lane & 15)) * K + 4 * (lane >> 4);
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        if (XPACK) xbase[mt] = p.xp + ((size_t)g * (M / 16) + mt) * (size_t)nch * 256 + lane * 4;
+        else xbase[mt] = p.x + ((size_t)g * M + mt * 16 + (lane & 15)) * K + 4 * (lane >> 4);
+    }
+    constexpr size_t WS = WPACK ? 256 : 16;  // floats per chunk step
+    constexpr size_t XS = XPACK ? 256 : 16;
+    f32x4 acc[NF][MT];
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[f][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int ngroups = nch / U;
+    const int ngw = ngroups > wave ? (ngroups - wave + WAVES - 1) / WAVES : 0;
+    const int glast = ngroups - 1;
+    float4 wc[U][NF], xc[U][MT], wn[U][NF], xn[U][MT];
+    auto LD = [&](float4 (&w)[U][NF], float4 (&x)[U][MT], int grp) {
+        const size_t c0 = (size_t)grp * U;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                const float4* a = reinterpret_cast<const float4*>(wbase[f] + (c0 + u) * WS);
+                if (NT) {
+                    f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a));
+                    w[u][f] = make_float4(v[0], v[1], v[2], v[3]);
+                } else w[u][f] = *a;
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) x[u][mt] = *reinterpret_cast<const float4*>(xbase[mt] + (c0 + u) * XS);
+        }
+    };
+    if (ngw > 0) LD(wc, xc, min(wave, glast));
+    for (int i = 0; i < ngw; ++i) {
+        LD(wn, xn, min(wave + (i + 1) * WAVES, glast));
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int f = 0; f < NF; ++f) {
+                    const float wv = j == 0 ? wc[u][f].x : j == 1 ? wc[u][f].y : j == 2 ? wc[u][f].z : wc[u][f].w;
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        const float xv = j == 0 ? xc[u][mt].x : j == 1 ? xc[u][mt].y : j == 2 ? xc[u][mt].z : xc[u][mt].w;
+                        acc[f][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, xv, acc[f][mt], 0, 0, 0);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int f = 0; f < NF; ++f) wc[u][f] = wn[u][f];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) xc[u][mt] = xn[u][mt];
+        }
+    }
+    __shared__ float red[WAVES][NF][MT][4][64];
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wave][f][mt][r][lane] = acc[f][mt][r];
+    __syncthreads();
+    for (int e = tid; e < NF * MT * 256; e += WAVES * 64) {
+        const int f = e / (MT * 256), mt = (e / 256) % MT, r = (e >> 6) & 3, l = e & 63;
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) s += red[w][f][mt][r][l];
+        const int n = (ntile * NF + f) * 16 + 4 * (l >> 4) + r, m = mt * 16 + (l & 15);
+        p.out[((size_t)g * M + m) * N + n] = s;
+    }
+}
+
+// pure streaming ceiling: read all of W with 1 KiB wave loads, sum, write one float per wave
+template <bool NT>
+__global__ __launch_bounds__(256) void k_stream(const float* w, size_t n4, float* out) {
+    const float4* p = reinterpret_cast<const float4*>(w);
+    float s = 0.f;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n4; i += 4 * stride) {
+        float4 a, b, c, d;
+        if (NT) {
+            f32x4 t0 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + i));
+            f32x4 t1 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + i + stride));
+            f32x4 t2 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + i + 2 * stride));
+            f32x4 t3 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + i + 3 * stride));
+            s += t0[0] + t1[1] + t2[2] + t3[3];
+        } else {
+            a = p[i]; b = p[i + stride]; c = p[i + 2 * stride]; d = p[i + 3 * stride];
+            s += a.x + b.y + c.z + d.w;
+        }
+    }
+    for (; i < n4; i += stride) s += p[i].x;
+    if (s == 123.456f) out[0] = s;
+}
+
+__global__ void k_pack(const float* src, float* dst, int R, int K) {  // [R][K] -> [R/16][K/16][64][4]
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;    // float4 index in dst
+    const size_t total = (size_t)R * K / 4;
+    if (i >= total) return;
+    const int lane = i & 63;
+    const size_t blk = i >> 6;
+    const int nch = K / 16;
+    const size_t rt = blk / nch, c = blk % nch;
+    const float4 v = *reinterpret_cast<const float4*>(src + (rt * 16 + (lane & 15)) * K + c * 16 + 4 * (lane >> 4));
+    reinterpret_cast<float4*>(dst)[i] = v;
+}
+
+struct Var { const char* name; void (*launch)(P, int G, hipStream_t); };
+
+template <int MT, int NF, int WAVES, int U, bool WP, bool XP, bool NT>
+void launch(P p, int G, hipStream_t st) {
+    dim3 grid(p.N / (16 * NF), 1, G);
+    hipLaunchKernelGGL((k_var<MT, NF, WAVES, U, WP, XP, NT>), grid, dim3(WAVES * 64), 0, st, p);
+}
+
+int main(int argc, char** argv) {
+    const int G = argc > 1 ? atoi(argv[1]) : 5, M = 32, K = 4096, N = 4096;
+    const int rounds = argc > 2 ? atoi(argv[2]) : 15;
+    const size_t wsz = (size_t)G * N * K, xsz = (size_t)G * M * K, osz = (size_t)G * M * N;
+    float *w, *wp, *x, *xp, *out, *ref;
+    CK(hipMalloc(&w, wsz * 4)); CK(hipMalloc(&wp, wsz * 4)); CK(hipMalloc(&x, xsz * 4)); CK(hipMalloc(&xp, xsz * 4));
+    CK(hipMalloc(&out, osz * 4)); CK(hipMalloc(&ref, osz * 4));
+    std::vector<float> hw(wsz), hx(xsz);
+    unsigned s = 12345;
+    auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xFFFF) / 32768.0f - 1.0f; };
+    for (auto& v : hw) v = rnd() * 0.02f;
+    for (auto& v : hx) v = rnd();
+    CK(hipMemcpy(w, hw.data(), wsz * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(x, hx.data(), xsz * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_pack, dim3((unsigned)((wsz / 4 + 255) / 256)), dim3(256), 0, 0, w, wp, G * N, K);
+    hipLaunchKernelGGL(k_pack, dim3((unsigned)((xsz / 4 + 255) / 256)), dim3(256), 0, 0, x, xp, G * M, K);
+    CK(hipDeviceSynchronize());
+    P p{x, xp, w, wp, out, M, K, N};
+
+    std::vector<Var> vars = {
+        {"v0 rowW rowX  NF1 W4 U4      ", launch<2, 1, 4, 4, false, false, false>},
+        {"v1 packW rowX NF1 W4 U4      ", launch<2, 1, 4, 4, true, false, false>},
+        {"v2 packW packX NF1 W4 U4     ", launch<2, 1, 4, 4, true, true, false>},
+        {"v3 packW packX NF2 W4 U2     ", launch<2, 2, 4, 2, true, true, false>},
+        {"v4 packW packX NF2 W8 U2     ", launch<2, 2, 8, 2, true, true, false>},
+        {"v5 packW packX NF1 W8 U4     ", launch<2, 1, 8, 4, true, true, false>},
+        {"v6 packW packX NF1 W4 U4 nt  ", launch<2, 1, 4, 4, true, true, true>},
+        {"v7 packW packX NF2 W4 U4     ", launch<2, 2, 4, 4, true, true, false>},
+        {"v8 packW packX NF4 W4 U2     ", launch<2, 4, 4, 2, true, true, false>},
+        {"v9 packW packX NF1 W4 U8     ", launch<2, 1, 4, 8, true, true, false>},
+        {"v10 rowW rowX NF2 W4 U2      ", launch<2, 2, 4, 2, false, false, false>},
+        {"v11 packW packX NF2 W8 U2 nt ", launch<2, 2, 8, 2, true, true, true>},
+        {"v12 packW packX NF1 W16 U2   ", launch<2, 1, 16, 2, true, true, false>},
+    };
+    hipStream_t st;
+    CK(hipStreamCreate(&st));
+    // reference = variant 0
+    p.out = ref; vars[0].launch(p, G, st); CK(hipStreamSynchronize(st));
+    std::vector<float> href(osz), hout(osz);
+    CK(hipMemcpy(href.data(), ref, osz * 4, hipMemcpyDeviceToHost));
+    p.out = out;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    std::vector<std::vector<float>> times(vars.size() + 2);
+    const double wbytes = (double)wsz * 4;
+    for (int r = 0; r < rounds + 2; ++r) {
+        for (size_t v = 0; v < vars.size(); ++v) {
+            CK(hipEventRecord(e0, st));
+            for (int rep = 0; rep < 4; ++rep) vars[v].launch(p, G, st);
+            CK(hipEventRecord(e1, st));
+            CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            if (r >= 2) times[v].push_back(ms / 4);
+            if (r == 0) {
+                CK(hipMemcpy(hout.data(), out, osz * 4, hipMemcpyDeviceToHost));
+                double err = 0, mx = 0;
+                for (size_t i = 0; i < osz; ++i) { err = std::max(err, (double)fabsf(hout[i] - href[i])); mx = std::max(mx, (double)fabsf(href[i])); }
+                printf("check %-32s max|d| = %.3e (max|ref| %.3e) %s\n", vars[v].name, err, mx, err <= 1e-4 * mx ? "ok" : "MISMATCH");
+                CK(hipMemset(out, 0, osz * 4));
+            }
+        }
+        for (int nt = 0; nt < 2; ++nt) {
+            CK(hipEventRecord(e0, st));
+            for (int rep = 0; rep < 4; ++rep) {
+                if (nt) hipLaunchKernelGGL(k_stream<true>, dim3(2048), dim3(256), 0, st, w, wsz / 4, out);
+                else hipLaunchKernelGGL(k_stream<false>, dim3(2048), dim3(256), 0, st, w, wsz / 4, out);
+            }
+            CK(hipEventRecord(e1, st));
+            CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            if (r >= 2) times[vars.size() + nt].push_back(ms / 4);
+        }
+    }
+    printf("G=%d members, M=%d, K=N=%d, weight bytes per launch = %.1f MB\n", G, M, K, wbytes / 1e6);
+    for (size_t v = 0; v < times.size(); ++v) {
+        auto t = times[v];
+        std::sort(t.begin(), t.end());
+        const char* nm = v < vars.size() ? vars[v].name : (v == vars.size() ? "stream read (plain)           " : "stream read (nt)              ");
+        printf("%-32s median %8.1f us  min %8.1f us   %7.0f GB/s (median)\n", nm, t[t.size() / 2] * 1e3, t[0] * 1e3, wbytes / (t[t.size() / 2] * 1e-3) / 1e9);
+    }
+    return 0;
+}
