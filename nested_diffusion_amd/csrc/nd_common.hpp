@@ -81,10 +81,11 @@ __device__ __forceinline__ float4 nd_ld16(const float* p) {
     return *reinterpret_cast<const float4*>(p);
 }
 
-// One fused skinny Linear on packed operands:
+// One skinny Linear on packed operands, for `nm` members that share the layer shape (K, N):
 //   MODE 0: out[m,n] = act(scale[t,n] * sum_k x[m,k] w[n,k] + shift[t,n])
 //   MODE 1: that value is not stored; its projection onto C rows is: part[m,c,tile] = sum_{n in tile} pw[c,n]*v
 //           -- lin3 + unetnorm3 + softplus + lin4 (latent_model.py:181-184) in one pass.
+//   MODE 2: split-K partial sums, no epilogue: part[slab, m, n] = sum_{k in slab} x[m,k] w[n,k]
 struct SkinnyDesc {
     const float* x;      // frag16 [M][K]
     const float* w;      // frag16 [N][K]   (nn.Linear weight, rows padded to 16 with zeros)
@@ -92,226 +93,120 @@ struct SkinnyDesc {
     const float* shift;  // [rows, N] or nullptr (=0)
     float* out;          // MODE 0: frag16 [M][N] if out_packed else row-major [M][N]
     const float* pw;     // [C, N]            (MODE 1)
-    float* part;         // [M, C, ceil(N/16)] (MODE 1)
+    float* part;         // MODE 1: [M, C, ceil(N/16)];  MODE 2: [S, Mpad, Npad]
     int K, N, C, act, out_packed;
 };
 
-// Grid: (ceil(N/16), ceil(M/(16*MT)), members).  One workgroup owns 16 output columns for 16*MT rows;
-// its WAVES waves split K (interleaved groups of U chunks) and are summed through LDS in a fixed
-// order, so results are bitwise reproducible.  MFMA 16x16x4 f32: A[i=l&15][k=l>>4] <- W rows,
-// B[k=l>>4][j=l&15] <- x rows, D[i=4*(l>>4)+r][j=l&15]; lane l's float4 holds k = 4*(l>>4)..+3 of a
-// chunk and element jj feeds MFMA jj (the k order inside a chunk is permuted identically for A and B).
-template <int MT, int WAVES, int U, int MODE, bool NT>
-__global__ __launch_bounds__(WAVES * 64) void k_skinny_fused(SkinnyDesc d0, const SkinnyDesc* __restrict__ table,
-                                                             int M, int t) {
-    const SkinnyDesc d = table ? table[blockIdx.z] : d0;
+// WORK DECOMPOSITION.  The nm*ceil(N/16) 16-column output fragments of a launch are numbered
+// member-major and dealt contiguously, NF per workgroup (grid.x); grid.y = 16*MT-row groups; grid.z =
+// k-slabs (MODE 2 only).  A wave keeps NF weight fragments and MT activation fragments per 16-float
+// k-chunk in registers, so an activation fragment is loaded once per NF weight fragments: bytes pulled
+// through L1 per weight byte = 1 + MT/NF.  That ratio, not HBM, is what bounds the NF=1 form (measured:
+// W-only 53 us, W + x from L2 85 us, MFMA-only 50 us, for 5 x 67 MB at M = 32); with NF chosen so that the
+// grid is one workgroup per CU (NF = fragments / 256) the kernel streams at 4.8-4.9 TB/s.
+// The WAVES waves of a workgroup split K (interleaved groups of U chunks) and are summed through LDS in
+// a fixed order => bitwise reproducible.  A workgroup whose fragment range crosses a member boundary
+// takes a single-buffered path that loads the x of its first and of its last member.
+// MFMA 16x16x4 f32: A[i=l&15][k=l>>4] <- W rows, B[k=l>>4][j=l&15] <- x rows, D[i=4*(l>>4)+r][j=l&15];
+// lane l's float4 holds k = 4*(l>>4)..+3 of a chunk and element jj feeds MFMA jj (same k permutation on
+// both operands).
+template <int MT, int NF, int WAVES, int U, int MODE, bool NT>
+__global__ __launch_bounds__(WAVES * 64) void k_skinny(SkinnyDesc d0, const SkinnyDesc* __restrict__ table, int nm,
+                                                       int M, int t, int cps) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int K = d.K, N = d.N;
-    const int nch = K >> 4;
-    const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 16 * MT;
-    const int mtiles = (M + 15) >> 4;
-    const float* wp = d.w + (size_t)blockIdx.x * nch * 256 + lane * 4;
-    const float* xp[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) xp[mt] = d.x + (size_t)min(blockIdx.y * MT + mt, mtiles - 1) * nch * 256 + lane * 4;
-    f32x4 acc[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int ngroups = nch / U;     // full groups of U chunks
-    const int ngw = ngroups > wave ? (ngroups - wave + WAVES - 1) / WAVES : 0;
-    const int glast = ngroups > 0 ? ngroups - 1 : 0;
-
-    float4 wc[U], xc[U][MT], wn[U], xn[U][MT];
-    if (ngw > 0) {
-        const size_t base = (size_t)min(wave, glast) * (U * 256);
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            wc[u] = nd_ld16<NT>(wp + base + u * 256);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) xc[u][mt] = nd_ld16<false>(xp[mt] + base + u * 256);
-        }
-    }
-    for (int i = 0; i < ngw; ++i) {
-        // prefetch the next group (clamped: the last iteration re-reads a valid group, unused)
-        const size_t base = (size_t)min(wave + (i + 1) * WAVES, glast) * (U * 256);
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            wn[u] = nd_ld16<NT>(wp + base + u * 256);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) xn[u][mt] = nd_ld16<false>(xp[mt] + base + u * 256);
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const float wv[4] = {wc[u].x, wc[u].y, wc[u].z, wc[u].w};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    const float xv = j == 0 ? xc[u][mt].x : j == 1 ? xc[u][mt].y : j == 2 ? xc[u][mt].z : xc[u][mt].w;
-                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[j], xv, acc[mt], 0, 0, 0);
-                }
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            wc[u] = wn[u];
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) xc[u][mt] = xn[u][mt];
-        }
-    }
-    // leftover chunks (K/16 not a multiple of U): chunk c goes to wave c % WAVES
-    for (int c = ngroups * U + wave; c < nch; c += WAVES) {
-        const float4 w4 = *reinterpret_cast<const float4*>(wp + (size_t)c * 256);
-        const float wv[4] = {w4.x, w4.y, w4.z, w4.w};
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const float4 x4 = *reinterpret_cast<const float4*>(xp[mt] + (size_t)c * 256);
-            const float xv[4] = {x4.x, x4.y, x4.z, x4.w};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[j], xv[j], acc[mt], 0, 0, 0);
-        }
-    }
-
-    // ---- cross-wave reduction (fixed order) + fused epilogue ----
-    __shared__ float red[WAVES][MT][4][64];
-    __shared__ __attribute__((aligned(16))) float tile[16 * MT][20];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) red[wave][mt][r][lane] = acc[mt][r];
-    __syncthreads();
-    const float* sc = d.scale ? d.scale + (size_t)t * N : nullptr;
-    const float* sh = d.shift ? d.shift + (size_t)t * N : nullptr;
-    for (int e = tid; e < MT * 256; e += WAVES * 64) {
-        const int mt = e >> 8, r = (e >> 6) & 3, l = e & 63;
-        float s = red[0][mt][r][l];
-#pragma unroll
-        for (int w = 1; w < WAVES; ++w) s += red[w][mt][r][l];
-        const int nl = 4 * (l >> 4) + r, ml = 16 * mt + (l & 15);
-        const int n = n0 + nl;
-        float v = 0.f;
-        if (n < N) {
-            const float a = sc ? sc[n] : 1.0f;
-            const float b = sh ? sh[n] : 0.0f;
-            v = nd_act(a * s + b, d.act);
-        }
-        tile[ml][nl] = v;
-    }
-    __syncthreads();
-    if (MODE == 0) {
-        if (d.out_packed) {
-            // the 16x16 block (m-tile, this n-tile) is one contiguous 1 KiB of the frag16 output
-            const int nchN = N >> 4;
-            for (int e = tid; e < MT * 64; e += WAVES * 64) {
-                const int mt = e >> 6, L = e & 63;
-                const int mtg = blockIdx.y * MT + mt;
-                if (mtg < mtiles) {
-                    const float4 v = *reinterpret_cast<const float4*>(&tile[16 * mt + (L & 15)][4 * (L >> 4)]);
-                    *reinterpret_cast<float4*>(d.out + ((size_t)mtg * nchN + blockIdx.x) * 256 + L * 4) = v;
-                }
-            }
-        } else {
-            for (int e = tid; e < 16 * MT * 16; e += WAVES * 64) {
-                const int ml = e >> 4, nl = e & 15;
-                const int m = m0 + ml, n = n0 + nl;
-                if (m < M && n < N) d.out[(size_t)m * N + n] = tile[ml][nl];
-            }
-        }
-    } else {
-        const int C = d.C, NTl = gridDim.x;
-        for (int e = tid; e < 16 * MT * C; e += WAVES * 64) {
-            const int ml = e / C, c = e - ml * C;
-            const int m = m0 + ml;
-            if (m < M) {
-                float s = 0.f;
-                const int nmax = min(16, N - n0);
-                for (int nl = 0; nl < nmax; ++nl) s += d.pw[(size_t)c * N + n0 + nl] * tile[ml][nl];
-                d.part[((size_t)m * C + c) * NTl + blockIdx.x] = s;
-            }
-        }
-    }
-}
-
-// ---- split-K variant for very wide inputs (K = 150528: encoder_x.0 and mapping linear1) ------
-struct SplitKDesc {
-    const float* x;   // frag16 [M][K]
-    const float* w;   // frag16 [N][K]
-    float* part;      // [S, Mpad, Npad] row-major slabs (Mpad, Npad multiples of 16)
-    int K, N, S, cps; // cps = 16-float chunks per k-slab
-};
-
-#define ND_SPK_NF 2     // 16-row W fragments per wave
-#define ND_SPK_WAVES 4  // workgroup n-tile = 16 * NF * WAVES = 128 rows
-#define ND_SPK_TILE_N (16 * ND_SPK_NF * ND_SPK_WAVES)
-
-// Grid: x = ntiles * S workgroups, y = m-groups, z = members.  Workgroups with equal blockIdx % 8
-// share an XCD (round-robin dispatch; speed only), so k-slabs are dealt to the 8 XCD groups and every
-// n-tile of one slab runs on the same XCD: the x slab is then fetched into that XCD's L2 once.
-template <int MT, bool NT>
-__global__ __launch_bounds__(ND_SPK_WAVES * 64) void k_skinny_splitk(SplitKDesc d0, const SplitKDesc* __restrict__ table,
-                                                                      int M) {
-    const SplitKDesc d = table ? table[blockIdx.z] : d0;
-    constexpr int NF = ND_SPK_NF;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int K = d.K, N = d.N, S = d.S;
-    const int ntiles = (N + ND_SPK_TILE_N - 1) / ND_SPK_TILE_N;
-    int slab, tileid;
-    if ((S & 7) == 0) {
-        const int xg = blockIdx.x & 7, idx = blockIdx.x >> 3;
-        slab = (idx / ntiles) * 8 + xg;
-        tileid = idx % ntiles;
-    } else {
-        slab = blockIdx.x / ntiles;
-        tileid = blockIdx.x % ntiles;
-    }
-    const int nch = K >> 4;
-    const int c0 = slab * d.cps, c1 = min(c0 + d.cps, nch);
-    const int nfr_total = (N + 15) >> 4, mtiles = (M + 15) >> 4;
-    const int nf0 = tileid * (NF * ND_SPK_WAVES) + wave * NF;     // first 16-row W fragment of this wave
+    const int K = table ? table[0].K : d0.K, N = table ? table[0].N : d0.N;
+    const int nch = K >> 4, nfr = (N + 15) >> 4, total = nm * nfr, mtiles = (M + 15) >> 4;
+    const int f0 = blockIdx.x * NF;
+    const int c0 = MODE == 2 ? blockIdx.z * cps : 0;
+    const int c1 = MODE == 2 ? min(c0 + cps, nch) : nch;
+    int gidx[NF];
     const float* wp[NF];
 #pragma unroll
-    for (int f = 0; f < NF; ++f) wp[f] = d.w + (size_t)min(nf0 + f, nfr_total - 1) * nch * 256 + lane * 4;
-    const float* xp[MT];
+    for (int f = 0; f < NF; ++f) {
+        const int fr = min(f0 + f, total - 1);
+        gidx[f] = fr / nfr;
+        const float* wb = table ? table[gidx[f]].w : d0.w;
+        wp[f] = wb + ((size_t)(fr - gidx[f] * nfr) * nch + c0) * 256 + lane * 4;
+    }
+    const int gA = gidx[0], gB = gidx[NF - 1];
+    const float *xA[MT], *xB[MT];
+    {
+        const float* xa = table ? table[gA].x : d0.x;
+        const float* xb = table ? table[gB].x : d0.x;
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) xp[mt] = d.x + (size_t)min(blockIdx.y * MT + mt, mtiles - 1) * nch * 256 + lane * 4;
-
+        for (int mt = 0; mt < MT; ++mt) {
+            const size_t off = ((size_t)min((int)blockIdx.y * MT + mt, mtiles - 1) * nch + c0) * 256 + lane * 4;
+            xA[mt] = xa + off;
+            xB[mt] = xb + off;
+        }
+    }
     f32x4 acc[NF][MT];
 #pragma unroll
     for (int f = 0; f < NF; ++f)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[f][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    constexpr int U = 2;
-    float4 wc[U][NF], xc[U][MT], wn[U][NF], xn[U][MT];
-    const int nsteps = (c1 - c0 + U - 1) / U;   // the last step may re-read a chunk; masked below
-    const int clast = c1 - 1;
-    if (nsteps > 0) {
+    // Epilogue operands are fetched NOW (their latency hides under the weight stream): each thread's
+    // scale/shift entries for the output elements it will finish, and the lin4 rows of MODE 1 into LDS.
+    constexpr int EPT = (MT * 256 + WAVES * 64 - 1) / (WAVES * 64);   // epilogue elements per thread
+    float esc[NF][EPT], esh[NF][EPT];
+    int eact = 0, eC = 0, epacked = 0;
+    __shared__ float pws[MODE == 1 ? NF : 1][MODE == 1 ? 8 : 1][16];
+    if (MODE != 2) {
+        eact = table ? table[0].act : d0.act;
+        eC = table ? table[0].C : d0.C;
+        epacked = table ? table[0].out_packed : d0.out_packed;
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const size_t off = (size_t)min(c0 + u, clast) * 256;
+        for (int f = 0; f < NF; ++f) {
+            const int fr = min(f0 + f, total - 1), g = gidx[f], n0 = (fr - g * nfr) * 16;
+            const float* scp = table ? table[g].scale : d0.scale;
+            const float* shp = table ? table[g].shift : d0.shift;
 #pragma unroll
-            for (int f = 0; f < NF; ++f) wc[u][f] = nd_ld16<NT>(wp[f] + off);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) xc[u][mt] = nd_ld16<false>(xp[mt] + off);
+            for (int q = 0; q < EPT; ++q) {
+                const int e = tid + q * WAVES * 64, l = e & 63, r = (e >> 6) & 3;
+                const int n = min(n0 + 4 * (l >> 4) + r, N - 1);
+                esc[f][q] = scp ? scp[(size_t)t * N + n] : 1.0f;
+                esh[f][q] = shp ? shp[(size_t)t * N + n] : 0.0f;
+            }
+            if (MODE == 1) {
+                const float* pwp = table ? table[g].pw : d0.pw;
+                if (tid < eC * 16) {
+                    const int c = tid >> 4, nl = tid & 15;
+                    pws[f][c][nl] = (n0 + nl < N) ? pwp[(size_t)c * N + n0 + nl] : 0.f;
+                }
+            }
         }
     }
-    for (int i = 0; i < nsteps; ++i) {
-        const int cn = c0 + (i + 1) * U;
+
+    const int nck = max(c1 - c0, 0);
+    const int ngroups = nck / U;     // full groups of U chunks
+    const int ngw = ngroups > wave ? (ngroups - wave + WAVES - 1) / WAVES : 0;
+    const int glast = ngroups > 0 ? ngroups - 1 : 0;
+
+    float4 wc[U][NF], xc[U][MT];
+    auto LDW = [&](float4 (&w)[U][NF], int grp) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const size_t off = (size_t)min(cn + u, clast) * 256;
+        for (int u = 0; u < U; ++u)
 #pragma unroll
-            for (int f = 0; f < NF; ++f) wn[u][f] = nd_ld16<NT>(wp[f] + off);
+            for (int f = 0; f < NF; ++f) w[u][f] = nd_ld16<NT>(wp[f] + ((size_t)grp * U + u) * 256);
+    };
+    auto LDX = [&](float4 (&x)[U][MT], const float* const (&xb)[MT], int grp) {
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) xn[u][mt] = nd_ld16<false>(xp[mt] + off);
-        }
+        for (int u = 0; u < U; ++u)
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const bool live = (c0 + i * U + u) < c1;   // wave-uniform
-            if (live) {
+            for (int mt = 0; mt < MT; ++mt) x[u][mt] = nd_ld16<false>(xb[mt] + ((size_t)grp * U + u) * 256);
+    };
+    if (gA == gB) {
+        float4 wn[U][NF], xn[U][MT];
+        if (ngw > 0) { LDW(wc, min(wave, glast)); LDX(xc, xA, min(wave, glast)); }
+        for (int i = 0; i < ngw; ++i) {
+            // prefetch the next group (clamped: the last iteration re-reads a valid group, unused)
+            const int gn = min(wave + (i + 1) * WAVES, glast);
+            LDW(wn, gn); LDX(xn, xA, gn);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
 #pragma unroll
                     for (int f = 0; f < NF; ++f) {
                         const float wv = j == 0 ? wc[u][f].x : j == 1 ? wc[u][f].y : j == 2 ? wc[u][f].z : wc[u][f].w;
@@ -321,30 +216,133 @@ __global__ __launch_bounds__(ND_SPK_WAVES * 64) void k_skinny_splitk(SplitKDesc 
                             acc[f][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, xv, acc[f][mt], 0, 0, 0);
                         }
                     }
-                }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+#pragma unroll
+                for (int f = 0; f < NF; ++f) wc[u][f] = wn[u][f];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) xc[u][mt] = xn[u][mt];
             }
         }
+    } else {
+        float4 xb[U][MT];
+        for (int i = 0; i < ngw; ++i) {
+            const int gn = wave + i * WAVES;
+            LDW(wc, gn); LDX(xc, xA, gn); LDX(xb, xB, gn);
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
+            for (int u = 0; u < U; ++u)
 #pragma unroll
-            for (int f = 0; f < NF; ++f) wc[u][f] = wn[u][f];
+                for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) xc[u][mt] = xn[u][mt];
+                    for (int f = 0; f < NF; ++f) {
+                        const float wv = j == 0 ? wc[u][f].x : j == 1 ? wc[u][f].y : j == 2 ? wc[u][f].z : wc[u][f].w;
+                        const bool useB = gidx[f] != gA;
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) {
+                            const float xa = j == 0 ? xc[u][mt].x : j == 1 ? xc[u][mt].y : j == 2 ? xc[u][mt].z : xc[u][mt].w;
+                            const float xv = j == 0 ? xb[u][mt].x : j == 1 ? xb[u][mt].y : j == 2 ? xb[u][mt].z : xb[u][mt].w;
+                            acc[f][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, useB ? xv : xa, acc[f][mt], 0, 0, 0);
+                        }
+                    }
         }
     }
-    // D[i = 4*(l>>4)+r (n)][j = l&15 (m)]: each lane owns 4 consecutive n of one row m -> float4 store
-    const int Mp = mtiles * 16, Np = nfr_total * 16;
+    // leftover chunks (chunk count not a multiple of U): chunk c goes to wave c % WAVES
+    for (int c = ngroups * U + wave; c < nck; c += WAVES) {
 #pragma unroll
-    for (int f = 0; f < NF; ++f) {
-        if (nf0 + f < nfr_total) {
-            const int n = (nf0 + f) * 16 + 4 * (lane >> 4);
+        for (int f = 0; f < NF; ++f) {
+            const float4 w4 = *reinterpret_cast<const float4*>(wp[f] + (size_t)c * 256);
+            const float wv[4] = {w4.x, w4.y, w4.z, w4.w};
+            const bool useB = gidx[f] != gA;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                const int mtg = blockIdx.y * MT + mt;
-                if (mtg < mtiles) {
-                    const int m = mtg * 16 + (lane & 15);
-                    *reinterpret_cast<float4*>(d.part + ((size_t)slab * Mp + m) * Np + n) =
-                        make_float4(acc[f][mt][0], acc[f][mt][1], acc[f][mt][2], acc[f][mt][3]);
+                const float4 x4 = *reinterpret_cast<const float4*>((useB ? xB[mt] : xA[mt]) + (size_t)c * 256);
+                const float xv[4] = {x4.x, x4.y, x4.z, x4.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[f][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[j], xv[j], acc[f][mt], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- per fragment: cross-wave reduction (fixed order) + epilogue ----
+    __shared__ float red[WAVES][MT][4][64];
+    __shared__ __attribute__((aligned(16))) float tile[16 * MT][20];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+        const int fr = f0 + f;
+        if (fr < total) {                           // uniform across the workgroup
+            if (f > 0) __syncthreads();
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[wave][mt][r][lane] = acc[f][mt][r];
+            __syncthreads();
+            const int g = gidx[f], nfi = fr - g * nfr, n0 = nfi * 16;
+            if (MODE == 2) {
+                float* partp = table ? table[g].part : d0.part;
+                // raw partial sums, [slab][Mp][Np]; lane l of the reduced tile owns n = 4*(l>>4)+r, m = l&15
+                const int Mp = mtiles * 16, Np = nfr * 16;
+                for (int e = tid; e < MT * 64; e += WAVES * 64) {
+                    const int mt = e >> 6, l = e & 63;
+                    const int mtg = blockIdx.y * MT + mt;
+                    if (mtg < mtiles) {
+                        float v[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float s = red[0][mt][r][l];
+#pragma unroll
+                            for (int w = 1; w < WAVES; ++w) s += red[w][mt][r][l];
+                            v[r] = s;
+                        }
+                        *reinterpret_cast<float4*>(partp + ((size_t)blockIdx.z * Mp + mtg * 16 + (l & 15)) * Np + n0 + 4 * (l >> 4)) =
+                            make_float4(v[0], v[1], v[2], v[3]);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < EPT; ++q) {
+                    const int e = tid + q * WAVES * 64;
+                    if (e < MT * 256) {
+                        const int mt = e >> 8, r = (e >> 6) & 3, l = e & 63;
+                        float s = red[0][mt][r][l];
+#pragma unroll
+                        for (int w = 1; w < WAVES; ++w) s += red[w][mt][r][l];
+                        const int nl = 4 * (l >> 4) + r, ml = 16 * mt + (l & 15);
+                        tile[ml][nl] = (n0 + nl < N) ? nd_act(esc[f][q] * s + esh[f][q], eact) : 0.f;
+                    }
+                }
+                __syncthreads();
+                const int m0 = blockIdx.y * 16 * MT;
+                if (MODE == 0) {
+                    float* outp = table ? table[g].out : d0.out;
+                    if (epacked) {
+                        // the 16x16 block (m-tile, this fragment) is one contiguous 1 KiB of the frag16 output
+                        for (int e = tid; e < MT * 64; e += WAVES * 64) {
+                            const int mt = e >> 6, L = e & 63;
+                            const int mtg = blockIdx.y * MT + mt;
+                            if (mtg < mtiles) {
+                                const float4 v = *reinterpret_cast<const float4*>(&tile[16 * mt + (L & 15)][4 * (L >> 4)]);
+                                *reinterpret_cast<float4*>(outp + ((size_t)mtg * nfr + nfi) * 256 + L * 4) = v;
+                            }
+                        }
+                    } else {
+                        for (int e = tid; e < 16 * MT * 16; e += WAVES * 64) {
+                            const int ml = e >> 4, nl = e & 15;
+                            const int m = m0 + ml, n = n0 + nl;
+                            if (m < M && n < N) outp[(size_t)m * N + n] = tile[ml][nl];
+                        }
+                    }
+                } else {
+                    float* partp = table ? table[g].part : d0.part;
+                    for (int e = tid; e < 16 * MT * eC; e += WAVES * 64) {
+                        const int ml = e / eC, c = e - ml * eC;
+                        const int m = m0 + ml;
+                        if (m < M) {
+                            float s = 0.f;
+#pragma unroll
+                            for (int nl = 0; nl < 16; ++nl) s += pws[MODE == 1 ? f : 0][MODE == 1 ? c : 0][nl] * tile[ml][nl];
+                            partp[((size_t)m * eC + c) * nfr + nfi] = s;
+                        }
+                    }
                 }
             }
         }
@@ -361,7 +359,7 @@ struct SplitKEpiDesc {
     int N, S, act, out_packed;
 };
 
-static __global__ __launch_bounds__(256) void k_splitk_epilogue(SplitKEpiDesc d0, const SplitKEpiDesc* __restrict__ table, int M) {
+static __global__ __launch_bounds__(256) void k_splitk_epilogue(SplitKEpiDesc d0, const SplitKEpiDesc* __restrict__ table, int M, int S) {
     const SplitKEpiDesc d = table ? table[blockIdx.z] : d0;
     const int N = d.N, Np = ((N + 15) >> 4) * 16, Mp = ((M + 15) >> 4) * 16;
     const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // float4 index over [Mp][Np]
@@ -369,7 +367,7 @@ static __global__ __launch_bounds__(256) void k_splitk_epilogue(SplitKEpiDesc d0
     const int m = (int)(q / (Np / 4)), n = (int)(q % (Np / 4)) * 4;
     const size_t slab = (size_t)Mp * Np;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int k = 0; k < d.S; ++k) {
+    for (int k = 0; k < S; ++k) {
         const float4 v = *reinterpret_cast<const float4*>(d.part + (size_t)k * slab + (size_t)m * Np + n);
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
@@ -390,41 +388,67 @@ static __global__ __launch_bounds__(256) void k_splitk_epilogue(SplitKEpiDesc d0
 
 // ---- host helpers ---------------------------------------------------------------------------
 static inline int nd_pick_mt(int M) { return M <= 16 ? 1 : (M <= 32 ? 2 : 4); }
-
-// number of k-slabs for the split-K path: enough workgroups for >= 2 per CU, multiple of 8 (XCD
-// groups), each slab at least 32 chunks (512 floats) deep.
-static inline int nd_pick_splitk(int K, int N) {
-    const int nch = K / 16;
-    const int ntiles = (N + ND_SPK_TILE_N - 1) / ND_SPK_TILE_N;
-    int S = (768 + ntiles - 1) / ntiles;
-    S = ((S + 7) / 8) * 8;
-    while (S > 8 && nch / S < 32) S -= 8;
-    if (nch / S < 1) S = 1;
-    return S;
-}
 static inline bool nd_use_splitk(int K) { return K >= 16384; }
-static inline size_t nd_splitk_part_floats(int M, int K, int N) {
-    return (size_t)nd_pick_splitk(K, N) * (size_t)(((M + 15) / 16) * 16) * (size_t)(((N + 15) / 16) * 16);
-}
 
-// Launch geometry for the fused kernel.  Few workgroups (one member, <= 2 per CU): 16 waves split K so
-// a CU still has enough loads in flight; many workgroups: 8 waves.  Weights bigger than what the
-// 256 MiB Infinity Cache can hold across consecutive steps are streamed with nontemporal loads.
-struct SkinnyLaunch { void* fn; dim3 grid; dim3 block; };
+struct SkinnyLaunch { void* fn; dim3 grid; dim3 block; int cps; int S; };
+
+// Geometry: NF = fragments per workgroup so that the grid is ~one workgroup per CU (256), at most 5
+// (register budget at MT = 2 with 16 waves); 16 waves for MT <= 2, 8 for MT = 4.  Weights larger than what
+// the 256 MiB Infinity Cache keeps across consecutive steps are streamed with nontemporal loads.
+// MODE 2 (split-K): S k-slabs in grid.z so that (fragment groups) x (row groups) x S >= 1024 workgroups.
 template <int MODE>
 static inline SkinnyLaunch nd_skinny_launch(int K, int N, int M, int nm) {
     const int mt = nd_pick_mt(M);
-    const dim3 grid((N + 15) / 16, (M + 16 * mt - 1) / (16 * mt), nm);
-    const long wgs = (long)grid.x * grid.y * grid.z;
-    const bool nt = (double)nm * N * (double)K * 4.0 > 160e6;
-    const bool wide = wgs <= 512 && mt <= 2;      // MT=4 x 16 waves would need > 64 KB of static LDS
-    SkinnyLaunch L{nullptr, grid, dim3(wide ? 1024 : 512)};
-#define ND_SK_PICK(MTV)                                                                                         \
-    L.fn = wide ? (nt ? (void*)k_skinny_fused<MTV, 16, 2, MODE, true> : (void*)k_skinny_fused<MTV, 16, 2, MODE, false>) \
-                : (nt ? (void*)k_skinny_fused<MTV, 8, 4, MODE, true> : (void*)k_skinny_fused<MTV, 8, 4, MODE, false>);
-    if (mt == 1) { ND_SK_PICK(1) } else if (mt == 2) { ND_SK_PICK(2) } else {
-        L.fn = nt ? (void*)k_skinny_fused<4, 8, 4, MODE, true> : (void*)k_skinny_fused<4, 8, 4, MODE, false>;
+    const int nfr = (N + 15) / 16, total = nm * nfr, nch = K / 16;
+    const int mgroups = (M + 16 * mt - 1) / (16 * mt);
+    const int nfmax = mt == 4 ? 2 : 5;
+    int nf = total / 256;
+    nf = nf < 1 ? 1 : (nf > nfmax ? nfmax : nf);
+    int S = 1, cps = nch;
+    if (MODE == 2) {
+        nf = total >= 256 ? 4 : (total >= 128 ? 2 : 1);
+        if (nf > nfmax) nf = nfmax;
+        const int gx = (total + nf - 1) / nf;
+        S = (1024 + gx * mgroups - 1) / (gx * mgroups);   // ~4+ workgroups per CU: even finish without a work queue
+        if (S < 1) S = 1;
+        while (S > 1 && nch / S < 64) --S;          // keep every slab >= 64 chunks (1024 floats) deep
+        cps = (nch + S - 1) / S;
+        S = (nch + cps - 1) / cps;
     }
-#undef ND_SK_PICK
+    const bool nt = (double)nm * N * (double)K * 4.0 > 160e6;
+    SkinnyLaunch L{nullptr, dim3((total + nf - 1) / nf, mgroups, S), dim3(mt == 4 ? 512 : 1024), cps, S};
+#define ND_SK(MTV, NFV, WV, UV) (nt ? (void*)k_skinny<MTV, NFV, WV, UV, MODE, true> : (void*)k_skinny<MTV, NFV, WV, UV, MODE, false>)
+    if (mt == 4) {
+        L.fn = nf == 1 ? ND_SK(4, 1, 8, 2) : ND_SK(4, 2, 8, 2);
+    } else if (mt == 2) {
+        switch (nf) {
+            case 1: L.fn = ND_SK(2, 1, 16, 2); break;
+            case 2: L.fn = ND_SK(2, 2, 16, 2); break;
+            case 3: L.fn = ND_SK(2, 3, 16, 2); break;
+            case 4: L.fn = ND_SK(2, 4, 16, 1); break;
+            default: L.fn = ND_SK(2, 5, 16, 1); break;
+        }
+    } else {
+        switch (nf) {
+            case 1: L.fn = ND_SK(1, 1, 16, 2); break;
+            case 2: L.fn = ND_SK(1, 2, 16, 2); break;
+            case 3: L.fn = ND_SK(1, 3, 16, 2); break;
+            case 4: L.fn = ND_SK(1, 4, 16, 2); break;
+            default: L.fn = ND_SK(1, 5, 16, 2); break;
+        }
+    }
+#undef ND_SK
     return L;
+}
+
+static inline size_t nd_splitk_part_floats(int M, int K, int N, int nm = 1) {
+    const SkinnyLaunch L = nd_skinny_launch<2>(K, N, M, nm);
+    return (size_t)L.S * (size_t)(((M + 15) / 16) * 16) * (size_t)(((N + 15) / 16) * 16);
+}
+
+static inline hipError_t nd_launch_skinny(const SkinnyLaunch& L, SkinnyDesc d0, const SkinnyDesc* table, int nm, int M, int t,
+                                          hipStream_t st) {
+    int cps = L.cps;
+    void* args[] = {&d0, &table, &nm, &M, &t, &cps};
+    return hipLaunchKernel(L.fn, L.grid, L.block, args, 0, st);
 }

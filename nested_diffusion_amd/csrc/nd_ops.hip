@@ -47,24 +47,15 @@ extern "C" int nd_linear(const float* x, const float* wpk, const float* scale, c
     int rc = nd_pack_rows(x, xpk, M, K, stream);
     if (rc != ND_OK) return rc;
     if (nd_use_splitk(K)) {
-        const int S = nd_pick_splitk(K, N), nch = K / 16;
-        SplitKDesc sd{xpk, wpk, part, K, N, S, (nch + S - 1) / S};
-        const int ntiles = (N + ND_SPK_TILE_N - 1) / ND_SPK_TILE_N;
-        const int mt = nd_pick_mt(M);
-        dim3 grid(ntiles * S, (M + 16 * mt - 1) / (16 * mt), 1);
-        if (mt == 1) hipLaunchKernelGGL((k_skinny_splitk<1, true>), grid, dim3(256), 0, st, sd, (const SplitKDesc*)nullptr, M);
-        else if (mt == 2) hipLaunchKernelGGL((k_skinny_splitk<2, true>), grid, dim3(256), 0, st, sd, (const SplitKDesc*)nullptr, M);
-        else hipLaunchKernelGGL((k_skinny_splitk<4, true>), grid, dim3(256), 0, st, sd, (const SplitKDesc*)nullptr, M);
-        SplitKEpiDesc se{part, scale, shift, out, N, S, act, 0};
+        const SkinnyLaunch L = nd_skinny_launch<2>(K, N, M, 1);
+        SkinnyDesc sd{xpk, wpk, nullptr, nullptr, nullptr, nullptr, part, K, N, 0, ND_ACT_NONE, 0};
+        HIP_CHECK(nd_launch_skinny(L, sd, nullptr, 1, M, 0, st));
+        SplitKEpiDesc se{part, scale, shift, out, N, L.S, act, 0};
         const size_t q = (size_t)(((M + 15) / 16) * 16) * (((N + 15) / 16) * 16) / 4;
-        hipLaunchKernelGGL(k_splitk_epilogue, dim3((unsigned)((q + 255) / 256)), dim3(256), 0, st, se, (const SplitKEpiDesc*)nullptr, M);
+        hipLaunchKernelGGL(k_splitk_epilogue, dim3((unsigned)((q + 255) / 256)), dim3(256), 0, st, se, (const SplitKEpiDesc*)nullptr, M, L.S);
     } else {
         SkinnyDesc d{xpk, wpk, scale, shift, out, nullptr, nullptr, K, N, 0, act, 0};
-        const SkinnyDesc* table = nullptr;
-        int t = 0;
-        const SkinnyLaunch L = nd_skinny_launch<0>(K, N, M, 1);
-        void* args[] = {&d, &table, &M, &t};
-        HIP_CHECK(hipLaunchKernel(L.fn, L.grid, L.block, args, 0, st));
+        HIP_CHECK(nd_launch_skinny(nd_skinny_launch<0>(K, N, M, 1), d, nullptr, 1, M, 0, st));
     }
     HIP_CHECK(hipGetLastError());
     return ND_OK;

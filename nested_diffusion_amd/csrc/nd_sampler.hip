@@ -52,6 +52,8 @@ struct MemberDev {
     const float* epart;    // [M, C, NT]
 };
 
+#define ND_MAX_C 8
+
 struct StepIO {             // per-launch tensors with a member-major leading stride
     const float* yhat;  size_t yhat_ms;    // [nm][B][C]
     const float* ymean; size_t ymean_ms;   // [nm][B][C]
@@ -88,80 +90,111 @@ __device__ __forceinline__ float nd_y0_reparam(float y, float ymean, float eps, 
     return 1.0f / sab_t * (y - (1.0f - sab_t) * ymean - eps * s_t);
 }
 
-// eps[m, c] = lin4.bias[c] + sum over the n-tiles of lin3's projected partials; fixed reduction
-// tree (thread-strided, wave shuffle, then waves in order) => reproducible.
-template <int NT_THREADS>
-__device__ __forceinline__ float nd_reduce_eps(const float* __restrict__ epart, int NT, int M, int m, int C, int c,
-                                               float* red /* [NT_THREADS/64] */) {
+// eps[m, c] = sum over the n-tiles of lin3's projected partials (lin4.bias added by the caller); fixed
+// reduction tree (thread-strided, wave shuffle, then waves in order) => reproducible.  All C classes
+// are reduced in one pass (C is a template parameter: everything stays in registers).
+template <int NT_THREADS, int C>
+__device__ __forceinline__ void nd_reduce_eps(const float* __restrict__ epart, int NT, int m, float* red /* [NT_THREADS/64][C] */,
+                                              float (&out)[C]) {
     const int tid = threadIdx.x;
-    float s = 0.f;
-    const float* row = epart + ((size_t)m * C + c) * NT;
-    for (int tl = tid; tl < NT; tl += NT_THREADS) s += row[tl];
+    float s[C];
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-    __syncthreads();
-    if ((tid & 63) == 0) red[tid >> 6] = s;
-    __syncthreads();
-    float tot = 0.f;
+    for (int c = 0; c < C; ++c) {
+        s[c] = 0.f;
+        const float* row = epart + ((size_t)m * C + c) * NT;
+        for (int tl = tid; tl < NT; tl += NT_THREADS) s[c] += row[tl];
+    }
 #pragma unroll
-    for (int w = 0; w < NT_THREADS / 64; ++w) tot += red[w];
-    return tot;
+    for (int c = 0; c < C; ++c)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s[c] += __shfl_down(s[c], off, 64);
+    if ((tid & 63) == 0)
+#pragma unroll
+        for (int c = 0; c < C; ++c) red[(tid >> 6) * C + c] = s[c];
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        float tot = 0.f;
+#pragma unroll
+        for (int w = 0; w < NT_THREADS / 64; ++w) tot += red[w * C + c];
+        out[c] = tot;
+    }
 }
 
 #define ND_HEAD_INIT 0    // y = noise[0] + y_T_mean                       (diffusion_utils.py:139-140)
 #define ND_HEAD_UPDATE 1  // y = posterior(y, eps(t_prev), noise[i])       (diffusion_utils.py:66-92)
 #define ND_HEAD_GIVEN 2   // y = y_in (single eps_theta evaluation)
-#define ND_MAX_C 8
 
 // Step head: finish the previous step (reduce eps, posterior update -> y_t), then the first
 // ConditionalLinear block of this step:  h1 = softplus(A1[t] * (lin1.W [y_t, yhat]) + C1[t]) * xe
 // (latent_model.py:173-177).  Grid (ceil(F/1024), M, members), 256 threads, 4 columns per thread.
+// Every thread computes y_t redundantly (C values), so nothing crosses threads after the reduce; the
+// table / xe / lin1 loads are issued before the reduction so their latency overlaps it.
+template <int C>
 __global__ __launch_bounds__(256) void k_step_head(const MemberDev* __restrict__ members, StepIO io, int mode, int i_step,
-                                                   int t_prev, int t, int B, int M, int maxM, int C, int F, int NT, int T) {
+                                                   int t_prev, int t, int B, int M, int maxM, int F, int NT, int T) {
     const MemberDev mb = members[blockIdx.z];
     const int z = blockIdx.z, m = blockIdx.y, b = m % B, tid = threadIdx.x;
-    __shared__ float red[4];
-    __shared__ float ysh[2 * ND_MAX_C];
-    const float* yhat = io.yhat + z * io.yhat_ms + (size_t)b * C;
+    __shared__ float red[4 * C];
+    const int n = blockIdx.x * 1024 + tid * 4;
+    const bool live = n < F;
+    const int nchF = F >> 4;
+    constexpr int C2 = 2 * C;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), cc = a, xe = a;
+    float w1[4][C2];
+    if (live) {
+        a = *reinterpret_cast<const float4*>(mb.A1 + (size_t)t * F + n);
+        cc = *reinterpret_cast<const float4*>(mb.C1 + (size_t)t * F + n);
+        xe = *reinterpret_cast<const float4*>(mb.xe + nd_pk(b, n, nchF));
+        const float* wrow = mb.lin1_w + (size_t)n * C2;     // 4 consecutive rows = 4*C2 contiguous floats
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int q = 0; q < C2; ++q) w1[j][q] = wrow[j * C2 + q];
+    }
     const int par_new = i_step & 1;                       // ybuf parity written by this step
     float* ynew = mb.ybuf + ((size_t)par_new * maxM + m) * C;
     const float* yold = mb.ybuf + ((size_t)(par_new ^ 1) * maxM + m) * C;
-
-    for (int c = 0; c < C; ++c) {
-        float yv;
-        if (mode == ND_HEAD_INIT) {
-            const float ymean = io.ymean[z * io.ymean_ms + (size_t)b * C + c];
-            yv = io.noise[z * io.noise_ms + ((size_t)0 * M + m) * C + c] + ymean;
-        } else if (mode == ND_HEAD_UPDATE) {
-            const float eps = nd_reduce_eps<256>(mb.epart, NT, M, m, C, c, red) + mb.lin4_b[c];
-            const float ymean = io.ymean[z * io.ymean_ms + (size_t)b * C + c];
-            const float zz = io.noise[z * io.noise_ms + ((size_t)i_step * M + m) * C + c];
-            yv = nd_posterior(yold[c], ymean, eps, zz, io.alphas[t_prev], io.omabs[t_prev], io.omabs[t_prev - 1]);
-        } else {
-            yv = io.y_in[z * io.yin_ms + (size_t)m * C + c];
-        }
-        if (tid == 0) {
-            ysh[c] = yv;
-            ysh[C + c] = yhat[c];
-            if (blockIdx.x == 0) {
-                ynew[c] = yv;
-                if (io.seq_out && mode != ND_HEAD_GIVEN) io.seq_out[z * io.seq_ms + ((size_t)i_step * M + m) * C + c] = yv;
-            }
-        }
-    }
-    __syncthreads();
-    const int n = blockIdx.x * 1024 + tid * 4;
-    if (n >= F) return;
-    const int C2 = 2 * C, nchF = F >> 4;
-    float u[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int q = 0; q < C2; ++q) {
-        const float yq = ysh[q];
+    float yv[C], yh[C], ym[C], zz[C], yo[C], eps[C];
+    float al = 0.f, s_t = 0.f, s_tm1 = 0.f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) u[j] += mb.lin1_w[(size_t)(n + j) * C2 + q] * yq;
+    for (int c = 0; c < C; ++c) {
+        yh[c] = io.yhat[z * io.yhat_ms + (size_t)b * C + c];
+        eps[c] = 0.f; ym[c] = 0.f; zz[c] = 0.f; yo[c] = 0.f;
     }
-    const float4 a = *reinterpret_cast<const float4*>(mb.A1 + (size_t)t * F + n);
-    const float4 cc = *reinterpret_cast<const float4*>(mb.C1 + (size_t)t * F + n);
-    const float4 xe = *reinterpret_cast<const float4*>(mb.xe + nd_pk(b, n, nchF));
+    if (mode != ND_HEAD_GIVEN) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            ym[c] = io.ymean[z * io.ymean_ms + (size_t)b * C + c];
+            zz[c] = io.noise[z * io.noise_ms + ((size_t)i_step * M + m) * C + c];
+        }
+    }
+    if (mode == ND_HEAD_UPDATE) {
+        al = io.alphas[t_prev]; s_t = io.omabs[t_prev]; s_tm1 = io.omabs[t_prev - 1];
+#pragma unroll
+        for (int c = 0; c < C; ++c) yo[c] = yold[c];
+        nd_reduce_eps<256, C>(mb.epart, NT, m, red, eps);
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        if (mode == ND_HEAD_INIT) yv[c] = zz[c] + ym[c];
+        else if (mode == ND_HEAD_UPDATE) yv[c] = nd_posterior(yo[c], ym[c], eps[c] + mb.lin4_b[c], zz[c], al, s_t, s_tm1);
+        else yv[c] = io.y_in[z * io.yin_ms + (size_t)m * C + c];
+        if (tid == 0 && blockIdx.x == 0) {
+            ynew[c] = yv[c];
+            if (io.seq_out && mode != ND_HEAD_GIVEN) io.seq_out[z * io.seq_ms + ((size_t)i_step * M + m) * C + c] = yv[c];
+        }
+    }
+    if (!live) return;
+    float u[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < C; ++q)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) u[j] += w1[j][q] * yv[q];
+#pragma unroll
+    for (int q = 0; q < C; ++q)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) u[j] += w1[j][C + q] * yh[q];
     float4 h;
     h.x = nd_softplus(a.x * u[0] + cc.x) * xe.x;
     h.y = nd_softplus(a.y * u[1] + cc.y) * xe.y;
@@ -170,17 +203,34 @@ __global__ __launch_bounds__(256) void k_step_head(const MemberDev* __restrict__
     *reinterpret_cast<float4*>(mb.h1 + nd_pk(m, n, nchF)) = h;
 }
 
+static void* head_fn(int C) {
+    switch (C) {
+        case 1: return (void*)k_step_head<1>;
+        case 2: return (void*)k_step_head<2>;
+        case 3: return (void*)k_step_head<3>;
+        case 4: return (void*)k_step_head<4>;
+        case 5: return (void*)k_step_head<5>;
+        case 6: return (void*)k_step_head<6>;
+        case 7: return (void*)k_step_head<7>;
+        default: return (void*)k_step_head<8>;
+    }
+}
+
 // Last step (t = 0): y_0 = y_0_reparam (diffusion_utils.py:96-111), or plain eps output for the
 // eps_theta entry point.  Grid (M, 1, members), 64 threads.
 // eps_only: 0 = y_0 of the loop, 1 = eps output, 2 = one p_sample step from io.y_in with the draw in
 // io.noise (t = par_cur), 3 = p_sample_t_1to0 from io.y_in.
+template <int C>
 __global__ __launch_bounds__(64) void k_step_final(const MemberDev* __restrict__ members, StepIO io, int eps_only, int par_cur,
-                                                   int B, int M, int maxM, int C, int NT, int T, float* eps_out, size_t eps_ms) {
+                                                   int B, int M, int maxM, int NT, int T, float* eps_out, size_t eps_ms) {
     const MemberDev mb = members[blockIdx.z];
     const int z = blockIdx.z, m = blockIdx.x, b = m % B;
-    __shared__ float red[1];
+    __shared__ float red[C];
+    float epsv[C];
+    nd_reduce_eps<64, C>(mb.epart, NT, m, red, epsv);
+#pragma unroll
     for (int c = 0; c < C; ++c) {
-        const float eps = nd_reduce_eps<64>(mb.epart, NT, M, m, C, c, red) + mb.lin4_b[c];
+        const float eps = epsv[c] + mb.lin4_b[c];
         if (threadIdx.x == 0) {
             if (eps_only == 1) {
                 eps_out[z * eps_ms + (size_t)m * C + c] = eps;
@@ -199,6 +249,19 @@ __global__ __launch_bounds__(64) void k_step_final(const MemberDev* __restrict__
                 if (io.seq_out) io.seq_out[z * io.seq_ms + ((size_t)T * M + m) * C + c] = y0;
             }
         }
+    }
+}
+
+static void* final_fn(int C) {
+    switch (C) {
+        case 1: return (void*)k_step_final<1>;
+        case 2: return (void*)k_step_final<2>;
+        case 3: return (void*)k_step_final<3>;
+        case 4: return (void*)k_step_final<4>;
+        case 5: return (void*)k_step_final<5>;
+        case 6: return (void*)k_step_final<6>;
+        case 7: return (void*)k_step_final<7>;
+        default: return (void*)k_step_final<8>;
     }
 }
 
@@ -257,7 +320,7 @@ struct nd_handle_s {
     std::vector<MemberHost> members;
     MemberDev* members_dev = nullptr;      // [K]
     SkinnyDesc* descs_dev = nullptr;       // [L_COUNT][K]
-    SplitKDesc* spk_dev = nullptr;         // [K]   encoder_x.0 (split-K form)
+    SkinnyDesc* spk_dev = nullptr;         // [K]   encoder_x.0 as split-K partial sums (MODE 2)
     SplitKEpiDesc* spke_dev = nullptr;     // [K]
     float *alphas = nullptr, *omabs = nullptr;
     float* xpack = nullptr;                // frag16 [maxB][D] image batch shared by all members
@@ -289,11 +352,11 @@ static void carve(nd_handle_s* h, char* base, size_t* total) {
     const size_t pB = ((mB + 15) / 16) * 16, pM = ((mM + 15) / 16) * 16;   // rows padded to whole 16-row tiles
     h->NT = (int)((F + 15) / 16);
     h->enc_splitk = nd_use_splitk(c.data_dim);
-    h->S0 = h->enc_splitk ? nd_pick_splitk(c.data_dim, c.hidden_dim) : 0;
+    h->S0 = h->enc_splitk ? nd_skinny_launch<2>(c.data_dim, c.hidden_dim, c.max_batch, 1).S : 0;
     Carver cv{base};
     h->members_dev = cv.take<MemberDev>(K);
     h->descs_dev = cv.take<SkinnyDesc>(L_COUNT * K);
-    h->spk_dev = cv.take<SplitKDesc>(K);
+    h->spk_dev = cv.take<SkinnyDesc>(K);
     h->spke_dev = cv.take<SplitKEpiDesc>(K);
     h->alphas = cv.take<float>(T);
     h->omabs = cv.take<float>(T);
@@ -311,7 +374,8 @@ static void carve(nd_handle_s* h, char* base, size_t* total) {
         m.ybuf = cv.take<float>(2 * mM * C);
         m.h1 = cv.take<float>(pM * F); m.h2 = cv.take<float>(pM * F);
         m.epart = cv.take<float>((size_t)h->NT * mM * C);
-        m.splitk = cv.take<float>(h->enc_splitk ? nd_splitk_part_floats((int)mB, (int)D, (int)H) : 1);
+        // split-K slabs: sized for the deepest split any (B <= max_batch, member count) launch can pick
+        m.splitk = cv.take<float>(h->enc_splitk ? (size_t)(D / 16 / 64 + 1) * pB * H : 1);
     }
     *total = cv.off;
 }
@@ -445,9 +509,8 @@ extern "C" int nd_load_member(nd_handle h, int k, const nd_member_weights* w, vo
     for (int l = 0; l < L_COUNT; ++l)
         HIP_CHECK(hipMemcpy(h->descs_dev + (size_t)l * c.n_members + k, &ds[l], sizeof(SkinnyDesc), hipMemcpyHostToDevice));
     if (h->enc_splitk) {
-        const int nch = D / 16;
-        SplitKDesc sd{h->xpack, m.w_enc0, m.splitk, D, H, h->S0, (nch + h->S0 - 1) / h->S0};
-        SplitKEpiDesc se{m.splitk, m.sc0, m.sh0, m.e0, H, h->S0, ND_ACT_SOFTPLUS, 1};
+        SkinnyDesc sd{h->xpack, m.w_enc0, nullptr, nullptr, nullptr, nullptr, m.splitk, D, H, C, ND_ACT_NONE, 0};
+        SplitKEpiDesc se{m.splitk, m.sc0, m.sh0, m.e0, H, 0 /* S is a launch argument */, ND_ACT_SOFTPLUS, 1};
         HIP_CHECK(hipMemcpy(h->spk_dev + k, &sd, sizeof sd, hipMemcpyHostToDevice));
         HIP_CHECK(hipMemcpy(h->spke_dev + k, &se, sizeof se, hipMemcpyHostToDevice));
     }
@@ -466,10 +529,7 @@ static int check_range(nd_handle_s* h, int m0, int nm) {
 
 template <int MODE>
 static hipError_t launch_skinny(const SkinnyDesc* table, int K, int N, int M, int t, int nm, hipStream_t st) {
-    SkinnyDesc d0{};
-    const SkinnyLaunch L = nd_skinny_launch<MODE>(K, N, M, nm);
-    void* args[] = {&d0, &table, &M, &t};
-    return hipLaunchKernel(L.fn, L.grid, L.block, args, 0, st);
+    return nd_launch_skinny(nd_skinny_launch<MODE>(K, N, M, nm), SkinnyDesc{}, table, nm, M, t, st);
 }
 
 extern "C" int nd_encode(nd_handle h, int m0, int nm, const float* x_dev, int B, void* stream) {
@@ -482,16 +542,11 @@ extern "C" int nd_encode(nd_handle h, int m0, int nm, const float* x_dev, int B,
     const int K = c.n_members, H = c.hidden_dim, F = c.feature_dim, D = c.data_dim;
     launch_pack(x_dev, h->xpack, B, D, st);       // images -> frag16 once; every member reads the same batch
     if (h->enc_splitk) {
-        const int ntiles = (H + ND_SPK_TILE_N - 1) / ND_SPK_TILE_N;
-        const int mt = nd_pick_mt(B);
-        dim3 grid(ntiles * h->S0, (B + 16 * mt - 1) / (16 * mt), nm);
-        const SplitKDesc* tb = h->spk_dev + m0;
-        if (mt == 1) hipLaunchKernelGGL((k_skinny_splitk<1, true>), grid, dim3(256), 0, st, SplitKDesc{}, tb, B);
-        else if (mt == 2) hipLaunchKernelGGL((k_skinny_splitk<2, true>), grid, dim3(256), 0, st, SplitKDesc{}, tb, B);
-        else hipLaunchKernelGGL((k_skinny_splitk<4, true>), grid, dim3(256), 0, st, SplitKDesc{}, tb, B);
+        const SkinnyLaunch L = nd_skinny_launch<2>(D, H, B, nm);
+        HIP_CHECK(nd_launch_skinny(L, SkinnyDesc{}, h->spk_dev + m0, nm, B, 0, st));
         const size_t q = (size_t)(((B + 15) / 16) * 16) * H / 4;
         hipLaunchKernelGGL(k_splitk_epilogue, dim3((unsigned)((q + 255) / 256), 1, nm), dim3(256), 0, st, SplitKEpiDesc{},
-                           (const SplitKEpiDesc*)(h->spke_dev + m0), B);
+                           (const SplitKEpiDesc*)(h->spke_dev + m0), B, L.S);
     } else {
         HIP_CHECK(launch_skinny<0>(h->descs_dev + (size_t)L_ENC0 * K + m0, D, H, B, 0, nm, st));
     }
@@ -552,12 +607,21 @@ static int check_rows(nd_handle_s* h, int B, int mc, int T) {
 static int single_eval(nd_handle_s* h, int member, StepIO io, int t, int final_mode, float* out, int B, int mc, hipStream_t st) {
     const nd_config& c = h->cfg;
     const int K = c.n_members, F = c.feature_dim, C = c.y_dim, M = B * mc;
-    hipLaunchKernelGGL(k_step_head, dim3((F + 1023) / 1024, M, 1), dim3(256), 0, st, (const MemberDev*)(h->members_dev + member), io,
-                       ND_HEAD_GIVEN, 0, 0, t, B, M, c.max_rows, C, F, h->NT, c.n_steps);
+    {
+        const MemberDev* mdev = h->members_dev + member;
+        int mode = ND_HEAD_GIVEN, istep = 0, tprev = 0, tt = t, Bv = B, Mv = M, maxM = c.max_rows, Fv = F, NT = h->NT, Tn = c.n_steps;
+        void* ah[] = {&mdev, &io, &mode, &istep, &tprev, &tt, &Bv, &Mv, &maxM, &Fv, &NT, &Tn};
+        HIP_CHECK(hipLaunchKernel(head_fn(C), dim3((F + 1023) / 1024, M, 1), dim3(256), ah, 0, st));
+    }
     HIP_CHECK(launch_skinny<0>(h->descs_dev + (size_t)L_LIN2 * K + member, F, F, M, t, 1, st));
     HIP_CHECK(launch_skinny<1>(h->descs_dev + (size_t)L_LIN3 * K + member, F, F, M, t, 1, st));
-    hipLaunchKernelGGL(k_step_final, dim3(M, 1, 1), dim3(64), 0, st, (const MemberDev*)(h->members_dev + member), io, final_mode, t, B, M,
-                       c.max_rows, C, h->NT, c.n_steps, out, (size_t)0);
+    {
+        const MemberDev* mdev = h->members_dev + member;
+        int fm = final_mode, tt = t, Bv = B, Mv = M, maxM = c.max_rows, NT = h->NT, Tn = c.n_steps;
+        size_t ems = 0;
+        void* af[] = {&mdev, &io, &fm, &tt, &Bv, &Mv, &maxM, &NT, &Tn, &out, &ems};
+        HIP_CHECK(hipLaunchKernel(final_fn(C), dim3(M, 1, 1), dim3(64), af, 0, st));
+    }
     HIP_CHECK(hipGetLastError());
     return ND_OK;
 }
@@ -628,6 +692,7 @@ static hipError_t emit_loop(nd_handle_s* h, Emitter& em, int m0, int nm, StepIO 
     SkinnyDesc d0{};
     const dim3 ghead((F + 1023) / 1024, M, nm);
     const SkinnyLaunch L2 = nd_skinny_launch<0>(F, F, M, nm), L3 = nd_skinny_launch<1>(F, F, M, nm);
+    int cps2 = L2.cps, cps3 = L3.cps;
     // probes: up to 8 steps spread over the loop (never step 0: its head is the cheap INIT form)
     const int want = h->profiling ? (T - 1 < 8 ? T - 1 : 8) : 0;
     const int stride = want > 0 ? (T - 1) / want : 0;
@@ -643,13 +708,13 @@ static hipError_t emit_loop(nd_handle_s* h, Emitter& em, int m0, int nm, StepIO 
         const bool probe = want > 0 && i >= 1 && probed < want && ((i - 1) % stride) == stride / 2;
         hipEvent_t* ev = probe ? &h->probe_events[4 * probed] : nullptr;
         if (probe) em.record(ev[0]);
-        void* ah[] = {&mdev, &io, &mode, &istep, &t_prev, &t, &B, &M, &maxM, &C, &F, &NT, &Tn};
-        em.emit((void*)k_step_head, ghead, dim3(256), ah);
+        void* ah[] = {&mdev, &io, &mode, &istep, &t_prev, &t, &B, &M, &maxM, &F, &NT, &Tn};
+        em.emit(head_fn(C), ghead, dim3(256), ah);
         if (probe) em.record(ev[1]);
-        void* a2[] = {&d0, &t2, &M, &t};
+        void* a2[] = {&d0, &t2, &nm, &M, &t, &cps2};
         em.emit(L2.fn, L2.grid, L2.block, a2);
         if (probe) em.record(ev[2]);
-        void* a3[] = {&d0, &t3, &M, &t};
+        void* a3[] = {&d0, &t3, &nm, &M, &t, &cps3};
         em.emit(L3.fn, L3.grid, L3.block, a3);
         if (probe) { em.record(ev[3]); ++probed; }
     }
@@ -657,8 +722,8 @@ static hipError_t emit_loop(nd_handle_s* h, Emitter& em, int m0, int nm, StepIO 
     int eps_only = 0, par_cur = (T - 1) & 1;
     float* eps_out = nullptr;
     size_t eps_ms = 0;
-    void* af[] = {&mdev, &io, &eps_only, &par_cur, &B, &M, &maxM, &C, &NT, &Tn, &eps_out, &eps_ms};
-    em.emit((void*)k_step_final, dim3(M, 1, nm), dim3(64), af);
+    void* af[] = {&mdev, &io, &eps_only, &par_cur, &B, &M, &maxM, &NT, &Tn, &eps_out, &eps_ms};
+    em.emit(final_fn(C), dim3(M, 1, nm), dim3(64), af);
     return em.err;
 }
 

@@ -20,7 +20,7 @@ int nd_set_err(int code, const char* fmt, ...);
 // takes element jj of every lane (k order permuted identically on both operands).
 // ---------------------------------------------------------------------------------------------
 #define GB_K 16
-#define GB_LD 20
+#define GB_LD 24   // 16 + 8 pad: ds_read_b128 of (row = l&15, k-quad = l>>4) is bank-conflict-free
 
 template <int BM, int BN>
 __global__ __launch_bounds__(256) void k_gemm_nt(const float* __restrict__ x, const float* __restrict__ w,
@@ -94,15 +94,18 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const float* __restrict__ x, co
         for (int i = 0; i < FM; ++i) fa[i] = *reinterpret_cast<const float4*>(&sA[buf][wr * WM + 16 * i + lr][lk]);
 #pragma unroll
         for (int j = 0; j < FN; ++j) fb[j] = *reinterpret_cast<const float4*>(&sB[buf][wc * WN + 16 * j + lr][lk]);
+        // k-quad outermost: 16 independent accumulators between two MFMAs on the same one (the f32 MFMA's
+        // dependent latency, 40 cycles, exceeds its 32-cycle issue interval)
 #pragma unroll
-        for (int i = 0; i < FM; ++i) {
-            const float av[4] = {fa[i].x, fa[i].y, fa[i].z, fa[i].w};
+        for (int q = 0; q < 4; ++q) {
 #pragma unroll
-            for (int j = 0; j < FN; ++j) {
-                const float bv[4] = {fb[j].x, fb[j].y, fb[j].z, fb[j].w};
+            for (int i = 0; i < FM; ++i) {
+                const float av = q == 0 ? fa[i].x : q == 1 ? fa[i].y : q == 2 ? fa[i].z : fa[i].w;
 #pragma unroll
-                for (int q = 0; q < 4; ++q)  // A = w rows (n), B = x rows (m): D[i=n][j=m]
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[q], av[q], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < FN; ++j) {
+                    const float bv = q == 0 ? fb[j].x : q == 1 ? fb[j].y : q == 2 ? fb[j].z : fb[j].w;
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv, av, acc[i][j], 0, 0, 0);   // D[i=n][j=m]
+                }
             }
         }
         if (ks + 1 < nk) {

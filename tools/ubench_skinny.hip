@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <vector>
 #include <cmath>
+#include <cstring>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
@@ -25,7 +26,7 @@ struct P {
 // WPACK/XPACK: operand in MFMA fragment order (every wave load = 1 KiB contiguous)
 // NF: 16-row W fragments per wave (workgroup n-tile = 16*NF); MT: 16-row x fragments; WAVES split K.
 // U: chunks per pipeline stage.  NT: nontemporal W loads.  ILV: interleave accumulators in the MFMA order.
-template <int MT, int NF, int WAVES, int U, bool WPACK, bool XPACK, bool NT>
+template <int MT, int NF, int WAVES, int U, bool WPACK, bool XPACK, bool NT, int ABL = 0>
 __global__ __launch_bounds__(WAVES * 64) void k_var(P p) {
     const int g = blockIdx.z;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -57,6 +58,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_var(P p) {
     const int glast = ngroups - 1;
     float4 wc[U][NF], xc[U][MT], wn[U][NF], xn[U][MT];
     auto LD = [&](float4 (&w)[U][NF], float4 (&x)[U][MT], int grp) {
+        if (ABL == 3) grp = 0;
         const size_t c0 = (size_t)grp * U;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -69,12 +71,17 @@ __global__ __launch_bounds__(WAVES * 64) void k_var(P p) {
                 } else w[u][f] = *a;
             }
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) x[u][mt] = *reinterpret_cast<const float4*>(xbase[mt] + (c0 + u) * XS);
+            for (int mt = 0; mt < MT; ++mt) {
+                if (ABL == 2) x[u][mt] = make_float4(1.f, 2.f, 3.f, 4.f);
+                else if (ABL == 4) x[u][mt] = *reinterpret_cast<const float4*>(xbase[mt] + (size_t)u * XS);
+                else if (ABL == 5) x[u][mt] = *reinterpret_cast<const float4*>(xbase[mt] + ((size_t)(grp & 7) * U + u) * XS);
+                else x[u][mt] = *reinterpret_cast<const float4*>(xbase[mt] + (c0 + u) * XS);
+            }
         }
     };
     if (ngw > 0) LD(wc, xc, min(wave, glast));
     for (int i = 0; i < ngw; ++i) {
-        LD(wn, xn, min(wave + (i + 1) * WAVES, glast));
+        if (ABL != 3 || i == 0) LD(wn, xn, min(wave + (i + 1) * WAVES, glast));
 #pragma unroll
         for (int u = 0; u < U; ++u) {
 #pragma unroll
@@ -85,7 +92,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_var(P p) {
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) {
                         const float xv = j == 0 ? xc[u][mt].x : j == 1 ? xc[u][mt].y : j == 2 ? xc[u][mt].z : xc[u][mt].w;
-                        acc[f][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, xv, acc[f][mt], 0, 0, 0);
+                        if (ABL == 1 || ABL == 2) { if (j == 0) acc[f][mt][0] += wv + xv; }
+                        else acc[f][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, xv, acc[f][mt], 0, 0, 0);
                     }
                 }
             }
@@ -152,12 +160,258 @@ __global__ void k_pack(const float* src, float* dst, int R, int K) {  // [R][K] 
     reinterpret_cast<float4*>(dst)[i] = v;
 }
 
+
+// Variant family 2: a workgroup owns WN*16 output columns; wave (wn, wk) streams n-fragment wn over the
+// k-groups wk, wk+WK, ...  The WN waves with equal wk read the SAME x fragments (L1 hits, or LDS when XLDS).
+// STAG: rotate every workgroup's k order by a blockIdx-dependent offset (spreads L2-channel hot spots).
+template <int MT, int WN, int WK, int U, bool NT, bool STAG, bool XLDS>
+__global__ __launch_bounds__(WN * WK * 64) void k_var2(P p) {
+    const int g = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave % WN, wk = wave / WN;
+    const int K = p.K, N = p.N, M = p.M;
+    const int nch = K >> 4;
+    const int nf = blockIdx.x * WN + wn;
+    const float* wbase = p.wp + ((size_t)g * (N / 16) + nf) * (size_t)nch * 256 + lane * 4;
+    const float* xbase[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) xbase[mt] = p.xp + ((size_t)g * (M / 16) + mt) * (size_t)nch * 256 + lane * 4;
+    f32x4 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int ngroups = nch / U;           // assume divisible by WK
+    const int ngw = ngroups / WK;
+    const int rot = STAG ? (int)((blockIdx.x * 7 + blockIdx.z * 3) % ngw) : 0;
+    __shared__ __attribute__((aligned(16))) float xs[XLDS ? WK : 1][2][XLDS ? MT * U * 256 : 4];
+    float4 wc[U], xc[U][MT], wn_[U], xn[U][MT];
+    auto grp_of = [&](int i) { int ii = i + rot; if (ii >= ngw) ii -= ngw; return wk + ii * WK; };
+    auto LDW = [&](float4 (&w)[U], int grp) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float* a = wbase + ((size_t)grp * U + u) * 256;
+            if (NT) { f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a)); w[u] = make_float4(v[0], v[1], v[2], v[3]); }
+            else w[u] = *reinterpret_cast<const float4*>(a);
+        }
+    };
+    auto LDX = [&](float4 (&x)[U][MT], int grp) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) x[u][mt] = *reinterpret_cast<const float4*>(xbase[mt] + ((size_t)grp * U + u) * 256);
+    };
+    auto MM = [&](float4 (&w)[U], float4 (&x)[U][MT]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float wv = j == 0 ? w[u].x : j == 1 ? w[u].y : j == 2 ? w[u].z : w[u].w;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const float xv = j == 0 ? x[u][mt].x : j == 1 ? x[u][mt].y : j == 2 ? x[u][mt].z : x[u][mt].w;
+                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, xv, acc[mt], 0, 0, 0);
+                }
+            }
+    };
+    if (!XLDS) {
+        LDW(wc, grp_of(0)); LDX(xc, grp_of(0));
+        for (int i = 0; i < ngw; ++i) {
+            const int gn = grp_of(i + 1 < ngw ? i + 1 : i);
+            LDW(wn_, gn); LDX(xn, gn);
+            MM(wc, xc);
+#pragma unroll
+            for (int u = 0; u < U; ++u) { wc[u] = wn_[u];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) xc[u][mt] = xn[u][mt]; }
+        }
+    } else {
+        // the WN waves of one k-split stage the x group (MT*U KiB) into LDS cooperatively: piece q of the group
+        // (q = mt*U + u) is loaded by wave q % WN; double-buffered, one __syncthreads per group.
+        constexpr int PIECES = MT * U;
+        auto STAGE = [&](int buf, int grp) {
+#pragma unroll
+            for (int q = 0; q < PIECES; ++q) {
+                if (q % WN == wn) {
+                    const int mt = q / U, u = q % U;
+                    const float4 v = *reinterpret_cast<const float4*>(xbase[mt] + ((size_t)grp * U + u) * 256);
+                    *reinterpret_cast<float4*>(&xs[wk][buf][q * 256 + lane * 4]) = v;
+                }
+            }
+        };
+        STAGE(0, grp_of(0));
+        LDW(wc, grp_of(0));
+        __syncthreads();
+        for (int i = 0; i < ngw; ++i) {
+            const int buf = i & 1;
+            const int gn = grp_of(i + 1 < ngw ? i + 1 : i);
+            LDW(wn_, gn);
+            if (i + 1 < ngw) STAGE(buf ^ 1, gn);
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) xc[u][mt] = *reinterpret_cast<const float4*>(&xs[wk][buf][(mt * U + u) * 256 + lane * 4]);
+            MM(wc, xc);
+#pragma unroll
+            for (int u = 0; u < U; ++u) wc[u] = wn_[u];
+            __syncthreads();
+        }
+    }
+    __shared__ float red[WK][WN][MT][4][64];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wk][wn][mt][r][lane] = acc[mt][r];
+    __syncthreads();
+    for (int e = tid; e < WN * MT * 256; e += WN * WK * 64) {
+        const int f = e / (MT * 256), mt = (e / 256) % MT, r = (e >> 6) & 3, l = e & 63;
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < WK; ++w) s += red[w][f][mt][r][l];
+        const int n = (blockIdx.x * WN + f) * 16 + 4 * (l >> 4) + r, m = mt * 16 + (l & 15);
+        p.out[((size_t)g * M + m) * N + n] = s;
+    }
+}
+
+template <int MT, int WN, int WK, int U, bool NT, bool STAG, bool XLDS>
+void launch2(P p, int G, hipStream_t st) {
+    dim3 grid(p.N / (16 * WN), 1, G);
+    hipLaunchKernelGGL((k_var2<MT, WN, WK, U, NT, STAG, XLDS>), grid, dim3(WN * WK * 64), 0, st, p);
+}
+
+// Variant family 3: balanced persistent partition.  The G*N/16 n-fragments are dealt contiguously, NF per
+// workgroup; a wave keeps NF W fragments + MT x fragments per chunk in registers, so x is loaded once per NF
+// W fragments (L1-miss traffic = W * (1 + MT/NF)).  A workgroup whose range crosses a member boundary loads
+// the x of its first and of its last member ("A" and "B"; identical addresses -> L1 hit when uniform).
+template <int MT, int NF, int WAVES, int U, bool NT>
+__global__ __launch_bounds__(WAVES * 64) void k_var3(P p, int G) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int K = p.K, N = p.N, M = p.M;
+    const int nch = K >> 4, nfr = N >> 4;
+    const int total = G * nfr;
+    const int f0 = blockIdx.x * NF;
+    const float* wbase[NF];
+    int gidx[NF];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+        const int fr = min(f0 + f, total - 1);
+        gidx[f] = fr / nfr;
+        wbase[f] = p.wp + (size_t)fr * (size_t)nch * 256 + lane * 4;
+    }
+    const int gA = gidx[0], gB = gidx[NF - 1];
+    const bool uniform = gA == gB;
+    const float *xA[MT], *xB[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        xA[mt] = p.xp + ((size_t)gA * (M / 16) + mt) * (size_t)nch * 256 + lane * 4;
+        xB[mt] = p.xp + ((size_t)gB * (M / 16) + mt) * (size_t)nch * 256 + lane * 4;
+    }
+    f32x4 acc[NF][MT];
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[f][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int ngroups = nch / U;
+    const int ngw = ngroups > wave ? (ngroups - wave + WAVES - 1) / WAVES : 0;
+    const int glast = ngroups - 1;
+    float4 wc[U][NF], xc[U][MT], wn[U][NF], xn[U][MT];
+    auto LDW = [&](float4 (&w)[U][NF], int grp) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                const float* a = wbase[f] + ((size_t)grp * U + u) * 256;
+                if (NT) { f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a)); w[u][f] = make_float4(v[0], v[1], v[2], v[3]); }
+                else w[u][f] = *reinterpret_cast<const float4*>(a);
+            }
+    };
+    auto LDX = [&](float4 (&x)[U][MT], const float* const (&xb)[MT], int grp) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) x[u][mt] = *reinterpret_cast<const float4*>(xb[mt] + ((size_t)grp * U + u) * 256);
+    };
+    if (uniform) {
+        if (ngw > 0) { LDW(wc, min(wave, glast)); LDX(xc, xA, min(wave, glast)); }
+        for (int i = 0; i < ngw; ++i) {
+            const int gn = min(wave + (i + 1) * WAVES, glast);
+            LDW(wn, gn); LDX(xn, xA, gn);
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int f = 0; f < NF; ++f) {
+                        const float wv = j == 0 ? wc[u][f].x : j == 1 ? wc[u][f].y : j == 2 ? wc[u][f].z : wc[u][f].w;
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) {
+                            const float xv = j == 0 ? xc[u][mt].x : j == 1 ? xc[u][mt].y : j == 2 ? xc[u][mt].z : xc[u][mt].w;
+                            acc[f][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, xv, acc[f][mt], 0, 0, 0);
+                        }
+                    }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+#pragma unroll
+                for (int f = 0; f < NF; ++f) wc[u][f] = wn[u][f];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) xc[u][mt] = xn[u][mt];
+            }
+        }
+    } else {
+        // boundary workgroup (at most G-1 of them): single-buffered, x of both members
+        float4 xb[U][MT];
+        for (int i = 0; i < ngw; ++i) {
+            const int gn = wave + i * WAVES;
+            LDW(wc, gn); LDX(xc, xA, gn); LDX(xb, xB, gn);
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int f = 0; f < NF; ++f) {
+                        const float wv = j == 0 ? wc[u][f].x : j == 1 ? wc[u][f].y : j == 2 ? wc[u][f].z : wc[u][f].w;
+                        const bool useB = gidx[f] != gA;
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) {
+                            const float xa = j == 0 ? xc[u][mt].x : j == 1 ? xc[u][mt].y : j == 2 ? xc[u][mt].z : xc[u][mt].w;
+                            const float xbv = j == 0 ? xb[u][mt].x : j == 1 ? xb[u][mt].y : j == 2 ? xb[u][mt].z : xb[u][mt].w;
+                            acc[f][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, useB ? xbv : xa, acc[f][mt], 0, 0, 0);
+                        }
+                    }
+        }
+    }
+    __shared__ float red[WAVES][NF][MT][4][64];
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wave][f][mt][r][lane] = acc[f][mt][r];
+    __syncthreads();
+    for (int e = tid; e < NF * MT * 256; e += WAVES * 64) {
+        const int f = e / (MT * 256), mt = (e / 256) % MT, r = (e >> 6) & 3, l = e & 63;
+        const int fr = f0 + f;
+        if (fr < total) {
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) s += red[w][f][mt][r][l];
+            const int g = fr / nfr, n = (fr % nfr) * 16 + 4 * (l >> 4) + r, m = mt * 16 + (l & 15);
+            p.out[((size_t)g * M + m) * N + n] = s;
+        }
+    }
+}
+
+template <int MT, int NF, int WAVES, int U, bool NT>
+void launch3(P p, int G, hipStream_t st) {
+    const int total = G * (p.N / 16);
+    dim3 grid((total + NF - 1) / NF, 1, 1);
+    hipLaunchKernelGGL((k_var3<MT, NF, WAVES, U, NT>), grid, dim3(WAVES * 64), 0, st, p, G);
+}
+
 struct Var { const char* name; void (*launch)(P, int G, hipStream_t); };
 
-template <int MT, int NF, int WAVES, int U, bool WP, bool XP, bool NT>
+template <int MT, int NF, int WAVES, int U, bool WP, bool XP, bool NT, int ABL = 0>
 void launch(P p, int G, hipStream_t st) {
     dim3 grid(p.N / (16 * NF), 1, G);
-    hipLaunchKernelGGL((k_var<MT, NF, WAVES, U, WP, XP, NT>), grid, dim3(WAVES * 64), 0, st, p);
+    hipLaunchKernelGGL((k_var<MT, NF, WAVES, U, WP, XP, NT, ABL>), grid, dim3(WAVES * 64), 0, st, p);
 }
 
 int main(int argc, char** argv) {
@@ -193,7 +447,51 @@ int main(int argc, char** argv) {
         {"v10 rowW rowX NF2 W4 U2      ", launch<2, 2, 4, 2, false, false, false>},
         {"v11 packW packX NF2 W8 U2 nt ", launch<2, 2, 8, 2, true, true, true>},
         {"v12 packW packX NF1 W16 U2   ", launch<2, 1, 16, 2, true, true, false>},
+        {"a1 W8U4nt loads only (no mfma)", launch<2, 1, 8, 4, true, true, true, 1>},
+        {"a2 W8U4nt W loads only       ", launch<2, 1, 8, 4, true, true, true, 2>},
+        {"a3 W8U4 mfma only (no loads) ", launch<2, 1, 8, 4, true, true, true, 3>},
+        {"a4 W8U4nt x from 4KiB (L1)   ", launch<2, 1, 8, 4, true, true, true, 4>},
+        {"a5 W8U4nt x from 32KiB       ", launch<2, 1, 8, 4, true, true, true, 5>},
+        {"v13 W8 U4 nt                 ", launch<2, 1, 8, 4, true, true, true>},
+        {"v14 W8 U8 nt                 ", launch<2, 1, 8, 8, true, true, true>},
+        {"v15 W16 U4 nt                ", launch<2, 1, 16, 4, true, true, true>},
+        {"v16 W4 U8 nt                 ", launch<2, 1, 4, 8, true, true, true>},
+        {"v17 NF2 W8 U4 nt             ", launch<2, 2, 8, 4, true, true, true>},
+        {"p1 NF5 W8 U2 nt persistent   ", launch3<2, 5, 8, 2, true>},
+        {"p2 NF5 W8 U1 nt persistent   ", launch3<2, 5, 8, 1, true>},
+        {"p3 NF5 W4 U2 nt persistent   ", launch3<2, 5, 4, 2, true>},
+        {"p4 NF5 W16 U1 nt persistent  ", launch3<2, 5, 16, 1, true>},
+        {"p5 NF5 W8 U2 persistent      ", launch3<2, 5, 8, 2, false>},
+        {"p6 NF5 W12 U1 nt persistent  ", launch3<2, 5, 12, 1, true>},
+        {"p7 NF1 W8 U4 nt (=v13 form)  ", launch3<2, 1, 8, 4, true>},
+        {"p8 NF5 W12 U2 nt persistent  ", launch3<2, 5, 12, 2, true>},
+        {"p9 NF4 W16 U1 nt persistent  ", launch3<2, 4, 16, 1, true>},
+        {"p10 NF4 W8 U2 nt persistent  ", launch3<2, 4, 8, 2, true>},
+        {"p11 NF4 W12 U2 nt persistent ", launch3<2, 4, 12, 2, true>},
+        {"p12 NF8 W8 U1 nt persistent  ", launch3<2, 8, 8, 1, true>},
+        {"p13 NF6 W12 U1 nt persistent ", launch3<2, 6, 12, 1, true>},
+        {"p14 NF3 W16 U2 nt persistent ", launch3<2, 3, 16, 2, true>},
+        {"p15 NF2 W16 U2 nt persistent ", launch3<2, 2, 16, 2, true>},
+        {"w1 WN1 WK8 U4 nt stag        ", launch2<2, 1, 8, 4, true, true, false>},
+        {"w2 WN2 WK4 U4 nt             ", launch2<2, 2, 4, 4, true, false, false>},
+        {"w3 WN4 WK2 U4 nt             ", launch2<2, 4, 2, 4, true, false, false>},
+        {"w4 WN4 WK2 U4 nt stag        ", launch2<2, 4, 2, 4, true, true, false>},
+        {"w5 WN4 WK4 U4 nt             ", launch2<2, 4, 4, 4, true, false, false>},
+        {"w6 WN8 WK1 U4 nt             ", launch2<2, 8, 1, 4, true, false, false>},
+        {"w7 WN4 WK2 U4 nt xlds        ", launch2<2, 4, 2, 4, true, false, true>},
+        {"w8 WN4 WK4 U4 nt xlds        ", launch2<2, 4, 4, 4, true, false, true>},
+        {"w9 WN8 WK2 U4 nt xlds        ", launch2<2, 8, 2, 4, true, false, true>},
+        {"w10 WN8 WK1 U4 nt xlds       ", launch2<2, 8, 1, 4, true, false, true>},
+        {"w11 WN4 WK2 U2 nt xlds       ", launch2<2, 4, 2, 2, true, false, true>},
+        {"w12 WN2 WK4 U4 nt xlds       ", launch2<2, 2, 4, 4, true, false, true>},
+        {"w13 WN8 WK2 U2 nt xlds stag  ", launch2<2, 8, 2, 2, true, true, true>},
     };
+    if (argc > 3) {
+        std::vector<Var> sel;
+        sel.push_back(vars[0]);
+        for (auto& v : vars) if (strstr(v.name, argv[3]) == v.name) sel.push_back(v);
+        vars = sel;
+    }
     hipStream_t st;
     CK(hipStreamCreate(&st));
     // reference = variant 0
@@ -217,7 +515,7 @@ int main(int argc, char** argv) {
                 CK(hipMemcpy(hout.data(), out, osz * 4, hipMemcpyDeviceToHost));
                 double err = 0, mx = 0;
                 for (size_t i = 0; i < osz; ++i) { err = std::max(err, (double)fabsf(hout[i] - href[i])); mx = std::max(mx, (double)fabsf(href[i])); }
-                printf("check %-32s max|d| = %.3e (max|ref| %.3e) %s\n", vars[v].name, err, mx, err <= 1e-4 * mx ? "ok" : "MISMATCH");
+                printf("check %-32s max|d| = %.3e (max|ref| %.3e) %s\n", vars[v].name, err, mx, err <= 1e-4 * mx ? "ok" : (vars[v].name[0]=='a' ? "(ablation)" : "MISMATCH"));
                 CK(hipMemset(out, 0, osz * 4));
             }
         }
