@@ -1,0 +1,132 @@
+"""CPU-only checks: the C-ABI library loads and exports every symbol include/nested_diffusion.h declares
+(no compute calls), the ctypes table matches the header, and the host-side logic (CLI, config, sharding)."""
+import argparse
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "nested_diffusion.h")
+
+
+def header_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(nd_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_declares_the_expected_surface():
+    names = header_functions()
+    for must in ("nd_create", "nd_load_member", "nd_encode", "nd_sample", "nd_eps_theta", "nd_p_sample", "nd_linear",
+                 "nd_gemm_bias_act", "nd_layernorm", "nd_attention", "nd_aggregate", "nd_last_error"):
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol():
+    from nested_diffusion_amd import _lib, build
+    build.build()                                   # hipcc cross-compiles for gfx950 without a GPU
+    lib = _lib.load()
+    names = header_functions()
+    assert sorted(_lib.SIGNATURES) == names, set(names) ^ set(_lib.SIGNATURES)
+    for n in names:
+        assert hasattr(lib, n), n
+    assert b"gfx950" in lib.nd_version()
+
+
+def test_abi_argument_validation_without_gpu():
+    """Pure host-side argument checks: they return error codes before any HIP call."""
+    from nested_diffusion_amd import _lib
+    lib = _lib.load()
+    cfg = _lib.NdConfig(2, 50, 64, 64, 10, 1, 4, 4)                 # data_dim not a multiple of 16
+    assert lib.nd_workspace_bytes(ctypes.byref(cfg)) == 0
+    h = ctypes.c_void_p()
+    assert lib.nd_create(ctypes.byref(cfg), ctypes.byref(h)) != 0
+    assert b"data_dim" in lib.nd_last_error()
+    good = _lib.NdConfig(2, 150528, 4096, 4096, 100, 5, 32, 32)
+    nbytes = lib.nd_workspace_bytes(ctypes.byref(good))
+    # packed weights (5 x 2.74 GB) + tables + activations: 13..16 GB at the headline config
+    assert 13e9 < nbytes < 17e9, nbytes
+    assert lib.nd_create(ctypes.byref(good), ctypes.byref(h)) == 0
+    assert lib.nd_encode(h, 0, 1, None, 4, None) != 0              # workspace not bound
+    assert lib.nd_destroy(h) == 0
+    assert lib.nd_linear(None, None, None, None, None, 1, 16, 1, 0, None, 0, None) != 0
+    assert lib.nd_packed_bytes(3, 32) == 16 * 32 * 4               # rows padded to 16
+    assert lib.nd_packed_bytes(3, 30) == 0
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from nested_diffusion_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.NdError, match="no CPU fallback"):
+        _lib.load()
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="CPU-only behaviour")
+def test_no_cpu_fallback():
+    from nested_diffusion_amd import _lib, ops
+    from nested_diffusion_amd.engine import EnsembleEngine
+    with pytest.raises(_lib.NdError):
+        EnsembleEngine(2, 48, 64, 64, 10)
+    with pytest.raises(_lib.NdError):
+        ops.linear(torch.zeros(2, 16), torch.zeros(4, 16))
+    with pytest.raises(_lib.NdError):
+        ops.aggregate(torch.zeros(3, 2, 2), 0.1737)
+
+
+def test_cli_accepts_the_reference_invocation():
+    """Flags of diffusion/testing_scripts/test.sh:24."""
+    from nested_diffusion_amd.main import build_parser, dict2namespace
+    argv = ("--test --device 0 --thread 8 --loss card_onehot_conditional --config configs/chest_x_ray.yml "
+            "--exp ./results/chest_x_ray/run --doc chest_x_ray --n_splits 1 --noise_perturbation 0 --low_resolution 0 "
+            "--brightness 0 --contrast 1 --crop 0 --attack_name None --eps 0 --ni --preprocess grayscaled").split()
+    a = build_parser().parse_args(argv)
+    assert a.test and a.ni and a.loss == "card_onehot_conditional" and a.preprocess == "grayscaled"
+    assert a.timesteps is None and a.mc_trials == 20 and a.covered == (0.0, 0.0)
+    with pytest.raises(SystemExit):
+        build_parser().parse_args(["--test", "--doc", "x"])          # --config / --preprocess are required
+    ns = dict2namespace({"a": {"b": 1, "c": [[1, 2]]}, "d": "x"})
+    assert ns.a.b == 1 and ns.a.c[0][1] == 2 and ns.d == "x"
+
+
+def test_schedule_and_temperature_match_pinned_tables():
+    import numpy as np
+    from nested_diffusion_amd.diffusion_utils import make_beta_schedule
+    from nested_diffusion_amd.runner import temperature_for
+    z = np.load(os.path.join(ROOT, "tests", "golden", "schedule.npz"))
+    for T in (10, 100, 1000):
+        assert np.array_equal(make_beta_schedule("linear", T, 1e-4, 0.02).float().numpy(), z[f"betas_{T}"])
+    for sched in ("cosine", "cosine_anneal", "quad", "sigmoid", "const", "jsd"):
+        assert np.array_equal(make_beta_schedule(sched, 50, 1e-4, 0.02).float().numpy(), z[f"betas_{sched}_50"])
+    with pytest.raises(ValueError):
+        make_beta_schedule("nope")
+    assert temperature_for("ChestXRay") == 0.1737 and temperature_for("ISICSkinCancerAtkPGD") == 0.3162
+    with pytest.raises(NotImplementedError):
+        temperature_for("MNIST")
+
+
+def test_shard_bounds_cover_and_balance():
+    from nested_diffusion_amd.dist import shard_bounds
+    for n in (0, 1, 7, 32, 70, 256):
+        for world in (1, 2, 3, 8):
+            cuts = [shard_bounds(n, r, world) for r in range(world)]
+            assert cuts[0][0] == 0 and cuts[-1][1] == n
+            assert all(cuts[i][1] == cuts[i + 1][0] for i in range(world - 1))
+            sizes = [hi - lo for lo, hi in cuts]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_bounds(4, 2, 2)
+
+
+def test_synthetic_loader_contract():
+    from nested_diffusion_amd.data import SyntheticLoader, get_test_loader
+    batches = list(SyntheticLoader(2, 3, 2, seed=5, size=32))
+    assert len(batches) == 2 and batches[0][0].shape == (3, 3, 32, 32) and batches[0][1].dtype == torch.int64
+    assert float(batches[0][0].min()) >= 0.0 and float(batches[0][0].max()) < 1.0
+    again = list(SyntheticLoader(2, 3, 2, seed=5, size=32))
+    assert torch.equal(batches[1][0], again[1][0])
+    with pytest.raises(NotImplementedError):
+        get_test_loader(argparse.Namespace(synthetic_batches=0), None)

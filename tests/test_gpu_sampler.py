@@ -140,3 +140,48 @@ def test_error_paths():
     bad = dict(p); bad["lin2.lin.weight"] = torch.zeros(8, 8)
     with pytest.raises(ValueError):
         eng.load_member(0, bad)
+
+
+def test_reference_default_batch_70_and_row_groups():
+    """B = 70 (configs/*.yml testing.batch_size) is not a multiple of 16: exercises padded row tiles, the
+    MT = 4 kernels and two row groups; M = B*mc = 140."""
+    from nested_diffusion_amd.engine import EnsembleEngine
+    D, H, Fd, C, T, B, mc = 96, 64, 96, 2, 6, 70, 2
+    p = ref_cpu.init_cond_model_params(D, H, Fd, C, T, True, seed=5)
+    eng = EnsembleEngine(C, D, H, Fd, T, n_members=1, max_batch=B, max_rows=B * mc)
+    eng.load_member(0, p)
+    alphas, omabs = ref_cpu.schedule_tables("linear", T, 1e-4, 0.02)
+    eng.set_schedule(alphas, omabs)
+    g = torch.Generator().manual_seed(1)
+    x = torch.rand(B, D, generator=g)
+    yhat = torch.softmax(torch.randn(1, B, C, generator=g), -1)
+    noise = torch.randn(1, T, B * mc, C, generator=g)
+    eng.encode(x)
+    xe = eng.member_buffer(0, 0, B).cpu()
+    assert (xe - ref_cpu.encoder_x(p, x)).abs().max() < 2e-5
+    y0 = eng.sample(yhat.cuda(), yhat.cuda(), noise.cuda(), mc=mc).cpu()[0]
+    for j in range(mc):
+        ref = ref_cpu.p_sample_loop(p, x, yhat[0], yhat[0], T, alphas, omabs, noise[0, :, j * B:(j + 1) * B])
+        assert (y0[j * B:(j + 1) * B] - ref).abs().max() < 5e-5 * max(1.0, ref.abs().max())
+
+
+def test_five_members_uneven_fragment_ranges():
+    """K = 5 members with F = 80 (5 fragments each): workgroups whose fragment range crosses a member boundary
+    take the two-activation path of k_skinny."""
+    from nested_diffusion_amd.engine import EnsembleEngine
+    D, H, Fd, C, T, B = 64, 48, 80, 2, 5, 9
+    ps = [ref_cpu.init_cond_model_params(D, H, Fd, C, T, True, seed=70 + k) for k in range(5)]
+    eng = EnsembleEngine(C, D, H, Fd, T, n_members=5, max_batch=B)
+    for k, p in enumerate(ps):
+        eng.load_member(k, p)
+    alphas, omabs = ref_cpu.schedule_tables("linear", T, 1e-4, 0.02)
+    eng.set_schedule(alphas, omabs)
+    g = torch.Generator().manual_seed(2)
+    x = torch.rand(B, D, generator=g)
+    yhat = torch.softmax(torch.randn(5, B, C, generator=g), -1)
+    noise = torch.randn(5, T, B, C, generator=g)
+    eng.encode(x)
+    y0 = eng.sample(yhat.cuda(), yhat.cuda(), noise.cuda()).cpu()
+    for k, p in enumerate(ps):
+        ref = ref_cpu.p_sample_loop(p, x, yhat[k], yhat[k], T, alphas, omabs, noise[k])
+        assert (y0[k] - ref).abs().max() < 5e-5 * max(1.0, ref.abs().max()), k
