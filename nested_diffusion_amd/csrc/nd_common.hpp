@@ -382,7 +382,8 @@ static __global__ __launch_bounds__(256) void k_splitk_epilogue(SplitKEpiDesc d0
     if (d.out_packed) {
         *reinterpret_cast<float4*>(d.out + nd_pk(m, n, N >> 4)) = make_float4(o[0], o[1], o[2], o[3]);
     } else if (m < M) {
-        for (int r = 0; r < 4 && n + r < N; ++r) d.out[(size_t)m * N + n + r] = o[r];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (n + r < N) d.out[(size_t)m * N + n + r] = o[r];
     }
 }
 

@@ -105,17 +105,41 @@ class GuidingConditioner:
 
     def __init__(self, vit: VisionTransformer, mlps: Sequence[Classifier]):
         self.vit, self.mlps = vit, list(mlps)
+        self._side = None
 
-    def compute_guiding_prediction(self, x: torch.Tensor, include_full_vit: bool = True) -> List[torch.Tensor]:
-        """classification_train_separately.py:330-348: list of K (+1) logits [B, C]."""
+    def compute_guiding_prediction(self, x: torch.Tensor, include_full_vit: bool = True, side_stream=None,
+                                   side_work=None) -> List[torch.Tensor]:
+        """classification_train_separately.py:330-348: list of K (+1) logits [B, C].
+
+        The ViT blocks are MFMA-bound, the mapping MLPs (2.5 GB of weights each) HBM-bound and independent of
+        the later blocks, so with `side_stream` the MLPs (and `side_work`, e.g. the noise estimators' encoder
+        hoist) run on a second HIP stream beside the ViT; the current stream waits for them at the end."""
         B = x.shape[0]
-        out: List[torch.Tensor] = []
+        out: List[torch.Tensor] = [None] * len(self.mlps)
+        main = torch.cuda.current_stream(x.device)
+        if side_stream is not None:
+            side_stream.wait_stream(main)
+            if side_work is not None:
+                with torch.cuda.stream(side_stream):
+                    side_work()
+        elif side_work is not None:
+            side_work()
         tok = self.vit.patch_embed(x)
         for i in range(1, len(self.mlps) + 1):
             tok = self.vit.block(i - 1, tok, B)       # prefix shared across members
-            out.append(self.mlps[i - 1](tok))
+            if side_stream is not None:
+                ev = torch.cuda.Event()
+                ev.record(main)
+                tok.record_stream(side_stream)
+                with torch.cuda.stream(side_stream):
+                    side_stream.wait_event(ev)
+                    out[i - 1] = self.mlps[i - 1](tok)
+            else:
+                out[i - 1] = self.mlps[i - 1](tok)
         if include_full_vit:
             out.append(self.vit.forward(x))
+        if side_stream is not None:
+            main.wait_stream(side_stream)
         return out
 
 

@@ -28,7 +28,7 @@ _ws_cache = {}
 
 
 def _workspace(nbytes: int, device) -> torch.Tensor:
-    key = (str(device),)
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream)   # one per stream: streams may run concurrently
     ws = _ws_cache.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)

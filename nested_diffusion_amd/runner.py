@@ -78,6 +78,8 @@ class Diffusion(object):
         self._states = noise_estimator_states
         self.engine: Optional[EnsembleEngine] = None
         self.members: List[int] = []
+        self.overlap_streams = bool(int(os.environ.get("ND_OVERLAP_STREAMS", "0")))
+        self._side_stream = None
 
     # ---- conditioner -------------------------------------------------------------------------
     def compute_guiding_prediction(self, x, include_full_vit: bool = True):
@@ -138,9 +140,14 @@ class Diffusion(object):
         B = images_224.shape[0]
         C = self.config.data.num_classes
         images_224_flat = torch.flatten(images_224, 1)                                  # :747
-        logits = self.compute_guiding_prediction(images_224, include_full_vit=False)    # :753 (6th never sampled)
+        if self._side_stream is None and self.overlap_streams:
+            self._side_stream = torch.cuda.Stream(self.device)
+        # :753 (6th element never sampled).  The encoder hoist and the mapping MLPs stream weights from HBM while
+        # the ViT blocks keep the matrix cores busy: they run on a second stream beside the ViT.
+        logits = self.cond_pred_model.compute_guiding_prediction(
+            images_224, include_full_vit=False, side_stream=self._side_stream if self.overlap_streams else None,
+            side_work=lambda: eng.encode(images_224_flat))
         yhat = torch.stack([ops.softmax_rows(logits[i]) for i in self.members])         # :755-758, [K,B,C]
-        eng.encode(images_224_flat)
         if noise is None:
             noise = torch.randn(K, T, B * mc, C, device=self.device)
         y0 = eng.sample(yhat, yhat, noise, mc=mc, T=T)                                  # :767-777 (y_T_mean = yhat, Q2)

@@ -1,0 +1,19 @@
+"""Shape sweep of nd_gemm_bias_act (ViT linears): TFLOP/s per shape, to separate kernel efficiency from tile quantisation."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from nested_diffusion_amd import ops
+
+def bench(M, K, N, act=None, reps=20):
+    x = torch.randn(M, K, device="cuda"); w = torch.randn(N, K, device="cuda") / K ** 0.5; b = torch.randn(N, device="cuda")
+    for _ in range(3): ops.gemm_bias_act(x, w, b, act=act)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); e0.record()
+    for _ in range(reps): ops.gemm_bias_act(x, w, b, act=act)
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / reps * 1e3
+    print(f"M={M:6d} K={K:5d} N={N:5d} act={act}: {us:8.1f} us  {2*M*K*N/us/1e6:7.1f} TFLOP/s")
+
+for shape in [(6272, 768, 2304), (6272, 768, 768), (6272, 768, 3072), (6272, 3072, 768), (8192, 768, 4096), (8192, 4096, 4096),
+              (4096, 4096, 4096), (16384, 768, 2048), (6272, 768, 3072, "gelu")]:
+    bench(*shape)
