@@ -53,9 +53,10 @@ def build_runner(args, device):
     return runner, cfg, cpu_member
 
 
-def cpu_baseline(member_cpu, x_flat_cpu, yhat_cpu, T_full, budget_s=20.0):
+def cpu_baseline(member_cpu, x_flat_cpu, yhat_cpu, T_full, budget_s=20.0, eng=None, temperature=0.1737):
     """CPU oracle, as-written mode (encoder re-evaluated every step, eager), one member, same B and dims.
-    Bounded sample: as many denoising steps as fit ~budget_s (every step is identical work)."""
+    Bounded sample: as many denoising steps as fit ~budget_s (every step is identical work).  The same
+    (member 0, noise, steps) sample is also run through the HIP path: `delta_vs_cpu` is the parity of the run."""
     from oracle import ref_cpu
     B, C = yhat_cpu.shape
     alphas, omabs = ref_cpu.schedule_tables("linear", T_full, 1e-4, 0.02)
@@ -65,9 +66,16 @@ def cpu_baseline(member_cpu, x_flat_cpu, yhat_cpu, T_full, budget_s=20.0):
     T_s = int(max(4, min(T_full, budget_s / max(per_step, 1e-3))))
     noise = torch.randn(T_s, B, C)
     t0 = time.perf_counter()
-    ref_cpu.p_sample_loop(member_cpu, x_flat_cpu, yhat_cpu, yhat_cpu, T_s, alphas, omabs, noise, True, hoist=False)
+    y_cpu = ref_cpu.p_sample_loop(member_cpu, x_flat_cpu, yhat_cpu, yhat_cpu, T_s, alphas, omabs, noise, True, hoist=False)
     dt = time.perf_counter() - t0
-    return {"value": B * T_s / dt, "unit": "denoising-step*images/s", "cores": torch.get_num_threads(), "kind": "port",
+    delta = None
+    if eng is not None:
+        dev = eng.device
+        y_gpu = eng.sample(yhat_cpu.to(dev)[None], yhat_cpu.to(dev)[None], noise.to(dev)[None], member0=0, n_members=1, mc=1, T=T_s)[0].cpu()
+        p_gpu, p_cpu = ref_cpu.convert_to_prob(y_gpu, temperature), ref_cpu.convert_to_prob(y_cpu, temperature)
+        delta = {"max_abs_y0": float((y_gpu - y_cpu).abs().max()), "max_abs_class_prob": float((p_gpu - p_cpu).abs().max()),
+                 "criterion": "class probabilities within 1e-3 (fp32)"}
+    return {"delta_vs_cpu": delta, "value": B * T_s / dt, "unit": "denoising-step*images/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"oracle/ref_cpu.py p_sample_loop as written (encoder re-evaluated each step), 1 of K members, "
                       f"B={B}, {T_s} of T={T_full} steps, fp32 torch CPU, {dt:.1f} s"}
 
@@ -187,7 +195,8 @@ def main():
         "sampler_only_value": units / (stages["sampler_ms"] * 1e-3),
     }
     if args.cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline(cpu_member, flat.cpu(), yhat[0].cpu(), T, args.cpu_seconds)
+        line["cpu_baseline"] = cpu_baseline(cpu_member, flat.cpu(), yhat[0].cpu(), T, args.cpu_seconds, eng=eng,
+                                            temperature=runner.temperature)
     else:
         line["cpu_baseline"] = None
     print(json.dumps(line))
