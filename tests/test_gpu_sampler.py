@@ -185,3 +185,34 @@ def test_five_members_uneven_fragment_ranges():
     for k, p in enumerate(ps):
         ref = ref_cpu.p_sample_loop(p, x, yhat[k], yhat[k], T, alphas, omabs, noise[k])
         assert (y0[k] - ref).abs().max() < 5e-5 * max(1.0, ref.abs().max()), k
+
+
+@pytest.mark.parametrize("B,mc,F_,C_", [(35, 3, 96, 2), (70, 2, 144, 3), (16, 9, 256, 2)])
+def test_large_m_row_groups(B, mc, F_, C_):
+    """M = B*mc > 64 rows (the reference's mc_trials = 20 regime): several 64-row groups per launch (MT = 4),
+    ragged row and column fragments, C = 3, two members."""
+    from nested_diffusion_amd.engine import EnsembleEngine
+    D, H, T = 64, 48, 5
+    ps = [ref_cpu.init_cond_model_params(D, H, F_, C_, T, True, seed=90 + k) for k in range(2)]
+    eng = EnsembleEngine(C_, D, H, F_, T, n_members=2, max_batch=B, max_rows=B * mc)
+    for k, p in enumerate(ps):
+        eng.load_member(k, p)
+    alphas, omabs = ref_cpu.schedule_tables("linear", T, 1e-4, 0.02)
+    eng.set_schedule(alphas, omabs)
+    g = torch.Generator().manual_seed(4)
+    x = torch.rand(B, D, generator=g)
+    yhat = torch.softmax(torch.randn(2, B, C_, generator=g), -1)
+    noise = torch.randn(2, T, B * mc, C_, generator=g)
+    eng.encode(x)
+    y0 = eng.sample(yhat.cuda(), yhat.cuda(), noise.cuda(), mc=mc).cpu()
+    assert torch.equal(eng.sample(yhat.cuda(), yhat.cuda(), noise.cuda(), mc=mc, use_graph=False).cpu(), y0)
+    for k, p in enumerate(ps):
+        for j in range(mc):
+            ref = ref_cpu.p_sample_loop(p, x, yhat[k], yhat[k], T, alphas, omabs, noise[k, :, j * B:(j + 1) * B])
+            got = y0[k, j * B:(j + 1) * B]
+            assert (got - ref).abs().max() < 5e-5 * max(1.0, ref.abs().max()), (k, j)
+    # single eps_theta evaluation through the same path
+    yy = torch.randn(B * mc, C_, generator=g)
+    eps = eng.eps_theta(1, yy, yhat[1], 2, mc=mc).cpu()
+    ref = ref_cpu.trunk(ps[1], ref_cpu.encoder_x(ps[1], x).repeat(mc, 1), yy, torch.tensor([2]), yhat[1].repeat(mc, 1))
+    assert (eps - ref).abs().max() < 5e-5 * max(1.0, ref.abs().max())
