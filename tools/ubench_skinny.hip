@@ -4,6 +4,7 @@
 // Each variant computes out[g][m][n] = sum_k x[g][m][k] * w[g][n][k] (checked against variant 0),
 // interleaved rounds in one process, median + min reported as GB/s of weight bytes.
 #include <hip/hip_runtime.h>
+#include "../nested_diffusion_amd/csrc/nd_common.hpp"
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -11,7 +12,6 @@
 #include <cmath>
 #include <cstring>
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
 struct P {
@@ -281,7 +281,7 @@ void launch2(P p, int G, hipStream_t st) {
 // workgroup; a wave keeps NF W fragments + MT x fragments per chunk in registers, so x is loaded once per NF
 // W fragments (L1-miss traffic = W * (1 + MT/NF)).  A workgroup whose range crosses a member boundary loads
 // the x of its first and of its last member ("A" and "B"; identical addresses -> L1 hit when uniform).
-template <int MT, int NF, int WAVES, int U, bool NT>
+template <int MT, int NF, int WAVES, int U, bool NT, int ABL = 0>
 __global__ __launch_bounds__(WAVES * 64) void k_var3(P p, int G) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int K = p.K, N = p.N, M = p.M;
@@ -333,7 +333,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_var3(P p, int G) {
         if (ngw > 0) { LDW(wc, min(wave, glast)); LDX(xc, xA, min(wave, glast)); }
         for (int i = 0; i < ngw; ++i) {
             const int gn = min(wave + (i + 1) * WAVES, glast);
-            LDW(wn, gn); LDX(xn, xA, gn);
+            LDW(wn, gn);
+            if (ABL != 2) LDX(xn, xA, gn);
 #pragma unroll
             for (int u = 0; u < U; ++u)
 #pragma unroll
@@ -344,7 +345,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_var3(P p, int G) {
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt) {
                             const float xv = j == 0 ? xc[u][mt].x : j == 1 ? xc[u][mt].y : j == 2 ? xc[u][mt].z : xc[u][mt].w;
-                            acc[f][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, xv, acc[f][mt], 0, 0, 0);
+                            if (ABL == 0) acc[f][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, xv, acc[f][mt], 0, 0, 0);
+                            else if (j == 0) acc[f][mt][0] += wv + xv;
                         }
                     }
 #pragma unroll
@@ -399,11 +401,111 @@ __global__ __launch_bounds__(WAVES * 64) void k_var3(P p, int G) {
     }
 }
 
-template <int MT, int NF, int WAVES, int U, bool NT>
+template <int MT, int NF, int WAVES, int U, bool NT, int ABL = 0>
 void launch3(P p, int G, hipStream_t st) {
     const int total = G * (p.N / 16);
     dim3 grid((total + NF - 1) / NF, 1, 1);
-    hipLaunchKernelGGL((k_var3<MT, NF, WAVES, U, NT>), grid, dim3(WAVES * 64), 0, st, p, G);
+    hipLaunchKernelGGL((k_var3<MT, NF, WAVES, U, NT, ABL>), grid, dim3(WAVES * 64), 0, st, p, G);
+}
+
+// Variant family 4: as family 3 (uniform workgroups only: benchmark G*N/16 divisible by NF), but the weight
+// fragments are prefetched TWO groups ahead (3 register stages for W, 2 for x) to keep more bytes in flight.
+template <int MT, int NF, int WAVES, bool NT>
+__global__ __launch_bounds__(WAVES * 64) void k_var4(P p, int G) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int K = p.K, N = p.N, M = p.M;
+    const int nch = K >> 4, nfr = N >> 4;
+    const int total = G * nfr;
+    const int f0 = blockIdx.x * NF;
+    const float* wbase[NF];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) wbase[f] = p.wp + (size_t)min(f0 + f, total - 1) * (size_t)nch * 256 + lane * 4;
+    const int gA = min(f0, total - 1) / nfr;
+    const float* xA[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) xA[mt] = p.xp + ((size_t)gA * (M / 16) + mt) * (size_t)nch * 256 + lane * 4;
+    f32x4 acc[NF][MT];
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[f][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int ngw = nch > wave ? (nch - wave + WAVES - 1) / WAVES : 0;   // U = 1: one chunk per group
+    const int glast = nch - 1;
+    float4 w0[NF], w1[NF], w2[NF], x0[MT], x1[MT];
+    auto LDW = [&](float4 (&w)[NF], int i) {
+        const size_t c = (size_t)min(wave + i * WAVES, glast);
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+            const float* a = wbase[f] + c * 256;
+            if (NT) { f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a)); w[f] = make_float4(v[0], v[1], v[2], v[3]); }
+            else w[f] = *reinterpret_cast<const float4*>(a);
+        }
+    };
+    auto LDX = [&](float4 (&x)[MT], int i) {
+        const size_t c = (size_t)min(wave + i * WAVES, glast);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) x[mt] = *reinterpret_cast<const float4*>(xA[mt] + c * 256);
+    };
+    auto MM = [&](float4 (&w)[NF], float4 (&x)[MT]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                const float wv = j == 0 ? w[f].x : j == 1 ? w[f].y : j == 2 ? w[f].z : w[f].w;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const float xv = j == 0 ? x[mt].x : j == 1 ? x[mt].y : j == 2 ? x[mt].z : x[mt].w;
+                    acc[f][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, xv, acc[f][mt], 0, 0, 0);
+                }
+            }
+    };
+    LDW(w0, 0); LDW(w1, 1); LDX(x0, 0);
+    int i = 0;
+    for (; i + 5 < ngw; i += 6) {          // 6 = lcm(3 W stages, 2 x stages)
+        LDW(w2, i + 2); LDX(x1, i + 1); MM(w0, x0);
+        LDW(w0, i + 3); LDX(x0, i + 2); MM(w1, x1);
+        LDW(w1, i + 4); LDX(x1, i + 3); MM(w2, x0);
+        LDW(w2, i + 5); LDX(x0, i + 4); MM(w0, x1);
+        LDW(w0, i + 6); LDX(x1, i + 5); MM(w1, x0);
+        LDW(w1, i + 7); LDX(x0, i + 6); MM(w2, x1);
+    }
+    for (; i < ngw; ++i) {                 // tail (ngw % 6 groups): simple reload
+        LDW(w0, i); LDX(x0, i); MM(w0, x0);
+    }
+    __shared__ float red[WAVES][NF][MT][4][64];
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wave][f][mt][r][lane] = acc[f][mt][r];
+    __syncthreads();
+    for (int e = tid; e < NF * MT * 256; e += WAVES * 64) {
+        const int f = e / (MT * 256), mt = (e / 256) % MT, r = (e >> 6) & 3, l = e & 63;
+        const int fr = f0 + f;
+        if (fr < total) {
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) s += red[w][f][mt][r][l];
+            const int g = fr / nfr, n = (fr % nfr) * 16 + 4 * (l >> 4) + r, m = mt * 16 + (l & 15);
+            p.out[((size_t)g * M + m) * N + n] = s;
+        }
+    }
+}
+template <int MT, int NF, int WAVES, bool NT>
+void launch4(P p, int G, hipStream_t st) {
+    const int total = G * (p.N / 16);
+    dim3 grid((total + NF - 1) / NF, 1, 1);
+    hipLaunchKernelGGL((k_var4<MT, NF, WAVES, NT>), grid, dim3(WAVES * 64), 0, st, p, G);
+}
+
+// ---- the library's own kernel (nd_common.hpp), driven through its launch helper ----
+static SkinnyDesc* g_tab = nullptr;   // [3][G]: MODE0 packed out, MODE1 projection, MODE0 row-major out
+static int g_G = 0, g_M = 0, g_K = 0, g_N = 0;
+template <int MODE, int WHICH>
+void launch_lib(P p, int G, hipStream_t st) {
+    const SkinnyLaunch L = nd_skinny_launch<MODE>(g_K, g_N, g_M, G);
+    nd_launch_skinny(L, SkinnyDesc{}, g_tab + (size_t)WHICH * g_G, G, g_M, /*t=*/3, st);
 }
 
 struct Var { const char* name; void (*launch)(P, int G, hipStream_t); };
@@ -432,6 +534,27 @@ int main(int argc, char** argv) {
     hipLaunchKernelGGL(k_pack, dim3((unsigned)((xsz / 4 + 255) / 256)), dim3(256), 0, 0, x, xp, G * M, K);
     CK(hipDeviceSynchronize());
     P p{x, xp, w, wp, out, M, K, N};
+    {
+        g_G = G; g_M = M; g_K = K; g_N = N;
+        float *scale, *shift, *pw, *part, *outp;
+        const int T = 8, C = 2;
+        CK(hipMalloc(&scale, (size_t)T * N * 4)); CK(hipMalloc(&shift, (size_t)T * N * 4)); CK(hipMalloc(&pw, (size_t)C * N * 4));
+        CK(hipMalloc(&part, (size_t)G * M * C * (N / 16) * 4)); CK(hipMalloc(&outp, (size_t)G * M * N * 4));
+        std::vector<float> ones((size_t)T * N, 1.0f);
+        CK(hipMemcpy(scale, ones.data(), (size_t)T * N * 4, hipMemcpyHostToDevice));
+        CK(hipMemset(shift, 0, (size_t)T * N * 4));
+        CK(hipMemcpy(pw, ones.data(), (size_t)C * N * 4, hipMemcpyHostToDevice));
+        std::vector<SkinnyDesc> tab(3 * G);
+        for (int g = 0; g < G; ++g) {
+            const float* xg = xp + (size_t)g * M * K;
+            const float* wg = wp + (size_t)g * N * K;
+            tab[0 * G + g] = SkinnyDesc{xg, wg, scale, shift, outp + (size_t)g * M * N, nullptr, nullptr, K, N, C, ND_ACT_SOFTPLUS, 1};
+            tab[1 * G + g] = SkinnyDesc{xg, wg, scale, shift, nullptr, pw, part + (size_t)g * M * C * (N / 16), K, N, C, ND_ACT_SOFTPLUS, 0};
+            tab[2 * G + g] = SkinnyDesc{xg, wg, nullptr, nullptr, out + (size_t)g * M * N, nullptr, nullptr, K, N, C, ND_ACT_NONE, 0};
+        }
+        CK(hipMalloc(&g_tab, tab.size() * sizeof(SkinnyDesc)));
+        CK(hipMemcpy(g_tab, tab.data(), tab.size() * sizeof(SkinnyDesc), hipMemcpyHostToDevice));
+    }
 
     std::vector<Var> vars = {
         {"v0 rowW rowX  NF1 W4 U4      ", launch<2, 1, 4, 4, false, false, false>},
@@ -457,6 +580,17 @@ int main(int argc, char** argv) {
         {"v15 W16 U4 nt                ", launch<2, 1, 16, 4, true, true, true>},
         {"v16 W4 U8 nt                 ", launch<2, 1, 4, 8, true, true, true>},
         {"v17 NF2 W8 U4 nt             ", launch<2, 2, 8, 4, true, true, true>},
+        {"L0 library k_skinny MODE 0   ", launch_lib<0, 0>},
+        {"L1 library k_skinny MODE 1   ", launch_lib<1, 1>},
+        {"r1 NF4 W16 3-stage nt (G=4)  ", launch4<2, 4, 16, true>},
+        {"r2 NF4 W12 3-stage nt (G=4)  ", launch4<2, 4, 12, true>},
+        {"r3 NF4 W8 3-stage nt (G=4)   ", launch4<2, 4, 8, true>},
+        {"r4 NF4 W16 U1 2-stage (G=4)  ", launch3<2, 4, 16, 1, true>},
+        {"q1 NF5 W16 U1 nt loads only  ", launch3<2, 5, 16, 1, true, 1>},
+        {"q2 NF5 W16 U1 nt W only      ", launch3<2, 5, 16, 1, true, 2>},
+        {"q3 NF5 W16 U1 nt full (=p4)  ", launch3<2, 5, 16, 1, true, 0>},
+        {"q4 NF5 W8 U2 nt W only       ", launch3<2, 5, 8, 2, true, 2>},
+        {"q5 NF5 W8 U2 nt loads only   ", launch3<2, 5, 8, 2, true, 1>},
         {"p1 NF5 W8 U2 nt persistent   ", launch3<2, 5, 8, 2, true>},
         {"p2 NF5 W8 U1 nt persistent   ", launch3<2, 5, 8, 1, true>},
         {"p3 NF5 W4 U2 nt persistent   ", launch3<2, 5, 4, 2, true>},
@@ -515,7 +649,7 @@ int main(int argc, char** argv) {
                 CK(hipMemcpy(hout.data(), out, osz * 4, hipMemcpyDeviceToHost));
                 double err = 0, mx = 0;
                 for (size_t i = 0; i < osz; ++i) { err = std::max(err, (double)fabsf(hout[i] - href[i])); mx = std::max(mx, (double)fabsf(href[i])); }
-                printf("check %-32s max|d| = %.3e (max|ref| %.3e) %s\n", vars[v].name, err, mx, err <= 1e-4 * mx ? "ok" : (vars[v].name[0]=='a' ? "(ablation)" : "MISMATCH"));
+                printf("check %-32s max|d| = %.3e (max|ref| %.3e) %s\n", vars[v].name, err, mx, err <= 1e-4 * mx ? "ok" : ((vars[v].name[0]=='a' || vars[v].name[0]=='q' || vars[v].name[0]=='r' || vars[v].name[0]=='L') ? "(ablation)" : "MISMATCH"));
                 CK(hipMemset(out, 0, osz * 4));
             }
         }
