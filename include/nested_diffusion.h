@@ -182,6 +182,26 @@ int nd_softmax_rows(const float *x_dev, float *out_dev, int rows, int C, void *s
 int nd_aggregate(const float *samples_dev, float *prob_out_dev, int64_t *vote_out_dev, float *probs_out_dev,
                  int S, int B, int C, float temperature, void *stream);
 
+/* ---- reporting tail of test_atk (classification_train_separately.py:801-838) --------------------- */
+/* Per-image spread of the S = K*mc per-sample probabilities (what the reference keeps in pred_mc, quirk Q4):
+ *   piw_out[B,C] = quantile(q_hi) - quantile(q_lo) over the samples (torch.quantile semantics: linear
+ *                  interpolation at rank q*(S-1));  compute_mean_piws_for_class :108-114 uses 0.025 / 0.975
+ *   var_out[B,C] = unbiased variance over the samples;  calculate_variances :166-172
+ * probs_dev [S,B,C]. */
+int nd_sample_stats(const float *probs_dev, float *piw_out_dev, float *var_out_dev, int S, int B, int C,
+                    float q_lo, float q_hi, void *stream);
+
+/* The numbers test_atk prints, over the whole test set (N images):
+ *   out[0]        majority-vote accuracy                                   (compute_accuracy :801-807)
+ *   out[1]        ECE: n_bins-bin l1 calibration error (torchmetrics 0.11.4 MulticlassCalibrationError) of
+ *                 convert_to_prob(prob_mean) -- the reference passes the averaged probabilities with prob_in=False,
+ *                 so they are transformed once more (:413-423, :812); kept as written
+ *   out[2+c], out[2+C+c]       mean PIW of class c over correct / incorrect votes (NaN if none; :124-140)
+ *   out[2+2C+c], out[2+3C+c]   mean variance of class c over correct / incorrect votes (0 if none; :150-172)
+ * piw_dev, var_dev, prob_mean_dev [N,C]; vote_dev, target_dev [N] int64; out_dev [2+4C]. */
+int nd_report(const float *piw_dev, const float *var_dev, const float *prob_mean_dev, const int64_t *vote_dev,
+              const int64_t *target_dev, float *out_dev, int N, int C, float temperature, int n_bins, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

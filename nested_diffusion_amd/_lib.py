@@ -76,6 +76,8 @@ SIGNATURES = {
     "nd_patchify": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "nd_softmax_rows": (_i, [_vp, _vp, _i, _i, _vp]),
     "nd_aggregate": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
+    "nd_sample_stats": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _f, _vp]),
+    "nd_report": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _vp]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -130,3 +130,123 @@ extern "C" int nd_aggregate(const float* samples, float* prob_out, int64_t* vote
     HIP_CHECK(hipGetLastError());
     return ND_OK;
 }
+
+
+// ---- reporting tail (classification_train_separately.py:102-174, 413-423, 801-815) ---------------
+// One wave per (image, class): the S per-sample values go to LDS; every lane ranks its elements by counting
+// (stable: ties broken by index), the four order statistics needed by the two interpolated quantiles are
+// picked by rank.  Variance: two-pass (mean, then centred squares), unbiased.
+#define ND_STATS_MAXS 4096
+__global__ __launch_bounds__(64) void k_sample_stats(const float* __restrict__ probs, float* __restrict__ piw, float* __restrict__ var,
+                                                     int S, int B, int C, float q_lo, float q_hi) {
+#pragma clang fp contract(off)
+    const int bc = blockIdx.x, lane = threadIdx.x;
+    __shared__ float v[ND_STATS_MAXS];
+    __shared__ float pick[4];
+    for (int s = lane; s < S; s += 64) v[s] = probs[(size_t)s * B * C + bc];
+    __syncthreads();
+    const float r_lo = q_lo * (float)(S - 1), r_hi = q_hi * (float)(S - 1);
+    const int k0 = (int)floorf(r_lo), k2 = (int)floorf(r_hi);
+    const int k1 = min(k0 + 1, S - 1), k3 = min(k2 + 1, S - 1);
+    float sum = 0.f;
+    for (int i = lane; i < S; i += 64) {
+        const float vi = v[i];
+        sum += vi;
+        int rank = 0;
+        for (int j = 0; j < S; ++j) rank += (v[j] < vi) || (v[j] == vi && j < i);
+        if (rank == k0) pick[0] = vi;
+        if (rank == k1) pick[1] = vi;
+        if (rank == k2) pick[2] = vi;
+        if (rank == k3) pick[3] = vi;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+    const float mean = sum / (float)S;
+    float sq = 0.f;
+    for (int i = lane; i < S; i += 64) { const float d = v[i] - mean; sq += d * d; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off, 64);
+    __syncthreads();
+    if (lane == 0) {
+        // torch.lerp(a, b, w): a + w*(b-a) for w < 0.5, else b - (b-a)*(1-w)
+        const float w_lo = r_lo - (float)k0, w_hi = r_hi - (float)k2;
+        const float lo = w_lo < 0.5f ? pick[0] + w_lo * (pick[1] - pick[0]) : pick[1] - (pick[1] - pick[0]) * (1.0f - w_lo);
+        const float hi = w_hi < 0.5f ? pick[2] + w_hi * (pick[3] - pick[2]) : pick[3] - (pick[3] - pick[2]) * (1.0f - w_hi);
+        piw[bc] = hi - lo;
+        var[bc] = S > 1 ? sq / (float)(S - 1) : NAN;
+    }
+}
+
+extern "C" int nd_sample_stats(const float* probs, float* piw, float* var, int S, int B, int C, float q_lo, float q_hi, void* stream) {
+    if (!probs || !piw || !var) return nd_set_err(ND_ERR_ARG, "NULL tensor");
+    if (S < 1 || S > ND_STATS_MAXS || B < 1 || C < 1) return nd_set_err(ND_ERR_ARG, "need 1 <= S <= %d, B,C >= 1", ND_STATS_MAXS);
+    if (!(q_lo >= 0.f && q_lo <= q_hi && q_hi <= 1.f)) return nd_set_err(ND_ERR_ARG, "need 0 <= q_lo <= q_hi <= 1");
+    hipLaunchKernelGGL(k_sample_stats, dim3(B * C), dim3(64), 0, (hipStream_t)stream, probs, piw, var, S, B, C, q_lo, q_hi);
+    HIP_CHECK(hipGetLastError());
+    return ND_OK;
+}
+
+// One thread per reported number, each a fixed-order loop over the N images (reproducible; N is a test-set size).
+#define ND_REPORT_MAXBINS 64
+__global__ __launch_bounds__(256) void k_report(const float* __restrict__ piw, const float* __restrict__ var, const float* __restrict__ pm,
+                                                const long long* __restrict__ vote, const long long* __restrict__ target,
+                                                float* __restrict__ out, int N, int C, float temperature, int n_bins) {
+#pragma clang fp contract(off)
+    const int tid = threadIdx.x;
+    __shared__ float ece_part[ND_REPORT_MAXBINS];
+    if (tid == 0) {                                         // accuracy
+        int correct = 0;
+        for (int i = 0; i < N; ++i) correct += vote[i] == target[i];
+        out[0] = (float)correct / (float)N;
+    }
+    if (tid >= 1 && tid <= n_bins) {                        // calibration bin tid-1: (b[k], b[k+1]]
+        const int k = tid - 1, steps = n_bins + 1;
+        const float step = 1.0f / (float)n_bins;
+        auto bound = [&](int i) { return i < steps / 2 ? step * (float)i : 1.0f - step * (float)(steps - 1 - i); };   // torch.linspace
+        const float lo = bound(k), hi = bound(k + 1);
+        float cnt = 0.f, csum = 0.f, asum = 0.f;
+        for (int i = 0; i < N; ++i) {
+            // convert_to_prob on the averaged probabilities (quirk kept), then confidence = max, prediction = argmax
+            float mx = -INFINITY, lg[16];
+            for (int c = 0; c < C; ++c) { const float d = pm[(size_t)i * C + c] - 1.0f; lg[c] = d * d * (-1.0f) / temperature; mx = fmaxf(mx, lg[c]); }
+            float sum = 0.f;
+            for (int c = 0; c < C; ++c) { lg[c] = expf(lg[c] - mx); sum += lg[c]; }
+            float conf = -1.f; int pred = 0;
+            for (int c = 0; c < C; ++c) { const float pc = lg[c] / sum; if (pc > conf) { conf = pc; pred = c; } }
+            if (conf > lo && conf <= hi) { cnt += 1.f; csum += conf; asum += (pred == (int)target[i]) ? 1.f : 0.f; }
+        }
+        ece_part[k] = cnt > 0.f ? fabsf(asum / cnt - csum / cnt) * (cnt / (float)N) : 0.f;
+    }
+    const int q = tid - 128;                                // class statistics: q = kind * C + c
+    if (q >= 0 && q < 4 * C) {
+        const int kind = q / C, c = q % C;                  // 0 piw correct, 1 piw incorrect, 2 var correct, 3 var incorrect
+        float sum = 0.f; int cnt = 0;
+        for (int i = 0; i < N; ++i) {
+            const int mv = (int)vote[i], gt = (int)target[i];
+            if (mv != c) continue;
+            const bool correct = mv == gt;
+            if ((kind & 1) == (correct ? 0 : 1)) {
+                sum += kind < 2 ? piw[(size_t)i * C + mv] : var[(size_t)i * C + c];
+                ++cnt;
+            }
+        }
+        out[2 + q] = kind < 2 ? sum / (float)cnt : (cnt > 0 ? sum / (float)cnt : 0.f);   // empty: NaN for PIW, 0 for variance
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float e = 0.f;
+        for (int k = 0; k < n_bins; ++k) e += ece_part[k];
+        out[1] = e;
+    }
+}
+
+extern "C" int nd_report(const float* piw, const float* var, const float* pm, const int64_t* vote, const int64_t* target, float* out,
+                         int N, int C, float temperature, int n_bins, void* stream) {
+    if (!piw || !var || !pm || !vote || !target || !out) return nd_set_err(ND_ERR_ARG, "NULL tensor");
+    if (N < 1 || C < 1 || C > 16 || n_bins < 1 || n_bins > ND_REPORT_MAXBINS) return nd_set_err(ND_ERR_ARG, "need N >= 1, 1 <= C <= 16, 1 <= n_bins <= %d", ND_REPORT_MAXBINS);
+    if (!(temperature > 0.f)) return nd_set_err(ND_ERR_ARG, "temperature must be > 0");
+    hipLaunchKernelGGL(k_report, dim3(1), dim3(256), 0, (hipStream_t)stream, piw, var, pm, (const long long*)vote, (const long long*)target, out,
+                       N, C, temperature, n_bins);
+    HIP_CHECK(hipGetLastError());
+    return ND_OK;
+}

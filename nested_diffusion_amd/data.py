@@ -23,7 +23,10 @@ class SyntheticLoader:
 def get_test_loader(args, config):
     n = int(getattr(args, "synthetic_batches", 0) or 0)
     if n > 0:
-        return SyntheticLoader(n, config.testing.batch_size, config.data.num_classes, seed=getattr(args, "seed", 0) or 0)
+        size = int(round((config.model.data_dim / 3) ** 0.5))          # 224 for data_dim = 150528 (3 x 224 x 224)
+        if 3 * size * size != config.model.data_dim:
+            raise ValueError(f"model.data_dim={config.model.data_dim} is not 3 x S x S")
+        return SyntheticLoader(n, config.testing.batch_size, config.data.num_classes, seed=getattr(args, "seed", 0) or 0, size=size)
     raise NotImplementedError(
         "disk datasets need torchvision's ImageFolder pipeline, which is outside the accelerated hot path; "
         "run with --synthetic_batches N (see INTEGRATION.md for wiring the reference's DataLoader in)")

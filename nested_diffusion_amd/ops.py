@@ -151,3 +151,31 @@ def aggregate(samples: torch.Tensor, temperature: float, return_probs: bool = Fa
     check(lib.nd_aggregate(ptr(samples), ptr(prob), ptr(vote), ptr(probs), S, B, C, float(temperature), _stream(samples)),
           "nd_aggregate")
     return prob, vote, probs
+
+
+def sample_stats(probs: torch.Tensor, q_lo: float = 0.025, q_hi: float = 0.975) -> Tuple[torch.Tensor, torch.Tensor]:
+    """probs [S, B, C] -> (PIW [B, C] = quantile(q_hi) - quantile(q_lo) over S, unbiased variance [B, C]).
+    compute_mean_piws_for_class :108-114, calculate_variances :166-172."""
+    lib = _lib.load()
+    probs = _f32(probs, "probs")
+    S, B, C = probs.shape
+    piw = torch.empty(B, C, dtype=torch.float32, device=probs.device)
+    var = torch.empty(B, C, dtype=torch.float32, device=probs.device)
+    check(lib.nd_sample_stats(ptr(probs), ptr(piw), ptr(var), S, B, C, float(q_lo), float(q_hi), _stream(probs)), "nd_sample_stats")
+    return piw, var
+
+
+def report(piw: torch.Tensor, var: torch.Tensor, prob_mean: torch.Tensor, vote: torch.Tensor, target: torch.Tensor,
+           temperature: float, n_bins: int = 10) -> dict:
+    """The numbers test_atk prints (classification_train_separately.py:801-838)."""
+    lib = _lib.load()
+    piw, var, prob_mean = _f32(piw, "piw"), _f32(var, "var"), _f32(prob_mean, "prob_mean")
+    N, C = prob_mean.shape
+    vote = vote.to(device=piw.device, dtype=torch.int64).contiguous()
+    target = target.to(device=piw.device, dtype=torch.int64).contiguous()
+    out = torch.empty(2 + 4 * C, dtype=torch.float32, device=piw.device)
+    check(lib.nd_report(ptr(piw), ptr(var), ptr(prob_mean), ptr(vote), ptr(target), ptr(out), N, C, float(temperature), int(n_bins),
+                        _stream(piw)), "nd_report")
+    o = out.cpu()
+    return {"accuracy": o[0], "ece": o[1], "piw_correct": o[2:2 + C], "piw_incorrect": o[2 + C:2 + 2 * C],
+            "var_correct": o[2 + 2 * C:2 + 3 * C], "var_incorrect": o[2 + 3 * C:2 + 4 * C]}

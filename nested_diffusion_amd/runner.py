@@ -157,8 +157,8 @@ class Diffusion(object):
 
     # ---- test loop ----------------------------------------------------------------------------
     def test_atk(self, test_loader=None):
-        """:631-840 reduced to the hot path + accuracy.  Input perturbations / attacks (:726-739) and the
-        PIW / ECE / variance report (:810-838) are the 'next' rows of SURVEY 8f and raise if requested."""
+        """:631-840: the hot path plus the report the reference prints (accuracy, ECE, per-class PIW and variances,
+        :801-838).  Input perturbations / attacks (:726-739) are 'next' rows of SURVEY 8f and raise if requested."""
         args, config = self.args, self.config
         for flag, off in (("noise_perturbation", 0.0), ("low_resolution", 0), ("brightness", 0.0), ("crop", 0.0)):
             v = getattr(args, flag, off) or off
@@ -175,22 +175,34 @@ class Diffusion(object):
         B = config.testing.batch_size
         lo, hi = nd_dist.shard_bounds(B, rank, world)
         self.load_noise_estimators(max_batch=max(hi - lo, 1))
-        mv_class, target_class, prob_mc = [], [], []
+        mv_class, target_class, prob_mc, piw_mc, var_mc = [], [], [], [], []
         n_step_img, t0 = 0, time.time()
         for images_raw, target in test_loader:
             images = images_raw[lo:hi].to(self.device, torch.float32)
             out = self.predict_batch(images)
-            prob = nd_dist.all_gather_rows(out["prob"], B, world)            # single RCCL all-gather of the logits
-            vote = nd_dist.all_gather_rows(out["vote"], B, world)
-            mv_class.append(vote.cpu()); target_class.append(target.cpu()); prob_mc.append(prob.cpu())
+            # spread of the K*mc per-sample probabilities per image (what the reference keeps in pred_mc, quirk Q4)
+            piw, var = ops.sample_stats(out["probs"])
+            packed = torch.cat([out["prob"], piw, var, out["vote"].to(torch.float32)[:, None]], dim=1)
+            packed = nd_dist.all_gather_rows(packed, B, world)               # the single RCCL all-gather of a batch
+            C = out["prob"].shape[1]
+            prob_mc.append(packed[:, :C]); piw_mc.append(packed[:, C:2 * C]); var_mc.append(packed[:, 2 * C:3 * C])
+            mv_class.append(packed[:, 3 * C].to(torch.int64)); target_class.append(target.to(self.device))
             n_step_img += B * len(self.members) * self.mc_trials * self.num_timesteps
         torch.cuda.synchronize(self.device)
         dt = time.time() - t0
-        pred, tgt = torch.cat(mv_class), torch.cat(target_class)
-        acc = (pred == tgt).float().mean()
+        rep = ops.report(torch.cat(piw_mc), torch.cat(var_mc), torch.cat(prob_mc), torch.cat(mv_class), torch.cat(target_class),
+                         self.temperature, n_bins=10)                        # :801-815
+        acc = rep["accuracy"]
         if rank == 0:
-            print(f"Majority voting accuracy for MC: {acc:.4f}")
-            logging.info("Majority voting accuracy for MC: %.4f \n", acc)
+            msg = (f"Majority voting accuracy for MC: {rep['accuracy'] :.4f} \n" +
+                   f"ECE: {rep['ece'] :.4f} \n" +
+                   f"Average correct PIW per class: {rep['piw_correct']} \n" +
+                   f"Average incorrect PIW per class: {rep['piw_incorrect']} \n" +
+                   f"Average correct variances per class: {rep['var_correct']} \n" +
+                   f"Average incorrect variances per class: {rep['var_incorrect']}")
+            print(msg)                                                       # :820-825
+            logging.info(msg + " \n")                                        # :829-838
             logging.info("throughput: %.1f denoising-step*images/s over %d GPU(s)", n_step_img / max(dt, 1e-9), world)
+        self.last_report = rep
         self.last_probs = torch.cat(prob_mc)
         return acc

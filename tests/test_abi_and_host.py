@@ -130,3 +130,7 @@ def test_synthetic_loader_contract():
     assert torch.equal(batches[1][0], again[1][0])
     with pytest.raises(NotImplementedError):
         get_test_loader(argparse.Namespace(synthetic_batches=0), None)
+    cfg = argparse.Namespace(model=argparse.Namespace(data_dim=3 * 32 * 32), testing=argparse.Namespace(batch_size=2),
+                             data=argparse.Namespace(num_classes=2))
+    x, y = next(iter(get_test_loader(argparse.Namespace(synthetic_batches=1, seed=3), cfg)))
+    assert x.shape == (2, 3, 32, 32)

@@ -1,0 +1,79 @@
+"""Drop-in CLI on the GPU: `main.py --test` with the reference's flags, a YAML in the reference's key layout and
+checkpoints written in the reference's three layouts (state_dict forms), synthetic test batches."""
+import argparse
+import os
+
+import pytest
+import torch
+import yaml
+
+from oracle import ref_cpu
+
+pytestmark = pytest.mark.gpu
+
+
+def _write_run(tmp, T=6, K=5, B=4):
+    embed, heads, depth, img, patch, C = 128, 2, 5, 32, 16, 2
+    D, H, F = 3 * img * img, 64, 64
+    ck = os.path.join(tmp, "ckpt")
+    os.makedirs(os.path.join(ck, "MLPs"))
+    vp = ref_cpu.init_vit_params(embed=embed, depth=depth, patch=patch, img=img, seed=3)
+    torch.save(vp, os.path.join(ck, "vit_base_patch16_224_ChestXRay.pth"))                 # state_dict form of :257
+    n_tok = (img // patch) ** 2
+    mlps = [ref_cpu.init_classifier_params(n_tok * embed, widths=(64, 32, 16), seed=20 + i) for i in range(K)]
+    for i, m in enumerate(mlps):
+        torch.save(m, os.path.join(ck, "MLPs", f"block_{i}.pth"))                          # mapping/train_mapping.py:160
+    members, paths = [], []
+    for i in range(K):
+        p = ref_cpu.init_cond_model_params(D, H, F, C, T, True, seed=40 + i)
+        members.append(p)
+        path = os.path.join(tmp, f"diffu{i}_ckpt_best_eph1_acc0.9000.pth")
+        torch.save({"noise_estimator": p, "optimizer": {}, "epoch": 1}, path)               # :1120-1126
+        paths.append(path)
+    cfg = {"data": {"dataset": "ChestXRay", "seed": 4444, "num_classes": C, "num_workers": 0, "dataroot": "PATH"},
+           "model": {"type": "simple", "data_dim": D, "feature_dim": F, "hidden_dim": H, "arch": "linear", "var_type": "fixedlarge"},
+           "diffusion": {"beta_schedule": "linear", "beta_start": 0.0001, "beta_end": 0.02, "timesteps": 1000, "vis_step": 100,
+                         "num_figs": 10, "include_guidance": True, "apply_aux_cls": True, "trained_aux_cls_ckpt_path": ck,
+                         "trained_diffusion_ckpt_path": [paths], "aux_cls": {"arch": "sevit"}},
+           "training": {"image_folder": "training_image_samples"}, "testing": {"batch_size": B}}
+    ypath = os.path.join(tmp, "chest_x_ray.yml")
+    yaml.safe_dump(cfg, open(ypath, "w"))
+    return ypath, vp, mlps, members, dict(embed=embed, heads=heads, depth=depth, img=img, D=D, C=C)
+
+
+def test_main_test_path_end_to_end(tmp_path, capsys, monkeypatch):
+    from nested_diffusion_amd import main as nd_main
+    from nested_diffusion_amd import mapping
+    T, K, B = 6, 5, 4
+    ypath, vp, mlps, members, dims = _write_run(str(tmp_path), T=T, K=K, B=B)
+    # the tiny ViT of this test has 2 heads of 64 (the real one 12): the loader's default is 12
+    orig = mapping.load_conditioner
+    monkeypatch.setattr(mapping, "load_conditioner", lambda path, ds, device="cuda", num_heads=12: orig(path, ds, device, dims["heads"]))
+    import nested_diffusion_amd.runner as runner_mod
+    monkeypatch.setattr(runner_mod, "load_conditioner", mapping.load_conditioner)
+    argv = ["--test", "--device", "0", "--thread", "8", "--loss", "card_onehot_conditional", "--config", ypath,
+            "--exp", os.path.join(str(tmp_path), "results"), "--doc", "chest_x_ray", "--n_splits", "1", "--noise_perturbation", "0",
+            "--low_resolution", "0", "--brightness", "0", "--contrast", "1", "--crop", "0", "--attack_name", "None", "--eps", "0",
+            "--ni", "--preprocess", "grayscaled", "--timesteps", str(T), "--seed", "7", "--synthetic_batches", "2", "--mc_trials", "3"]
+    rc = nd_main.main(argv)
+    assert rc == 0
+    out = capsys.readouterr().out
+    for key in ("Majority voting accuracy for MC:", "ECE:", "Average correct PIW per class:", "Average incorrect variances per class:"):
+        assert key in out, out
+    log = os.path.join(str(tmp_path), "results", "logs", "chest_x_ray", "split_0")
+    assert os.path.exists(os.path.join(log, "config.yml")) and os.path.exists(os.path.join(log, "stdout.txt"))
+    txt = open(os.path.join(log, "stdout.txt")).read()
+    assert "Testing procedure finished" in txt and "Traceback" not in txt, txt
+    saved = yaml.unsafe_load(open(os.path.join(log, "config.yml")))
+    assert saved.diffusion.timesteps == T                                   # --timesteps override (main.py:192-193)
+
+
+def test_main_swallows_errors_like_the_reference(tmp_path, capsys):
+    """main.py:377-380: any exception is logged with a traceback and the process still returns 0."""
+    from nested_diffusion_amd import main as nd_main
+    ypath, *_ = _write_run(str(tmp_path))
+    argv = ["--test", "--loss", "card_onehot_conditional", "--config", ypath, "--exp", os.path.join(str(tmp_path), "r"), "--doc", "d",
+            "--ni", "--preprocess", "grayscaled", "--timesteps", "6", "--brightness", "0.3", "--synthetic_batches", "1"]
+    assert nd_main.main(argv) == 0
+    txt = open(os.path.join(str(tmp_path), "r", "logs", "d", "split_0", "stdout.txt")).read()
+    assert "NotImplementedError" in txt and "--brightness" in txt

@@ -127,3 +127,33 @@ def test_ops_reject_cpu_tensors_and_bad_shapes():
         ops.attention(torch.zeros(4, 3 * 32).cuda(), 1, 4, 1)                  # head dim 32
     with pytest.raises(ValueError):
         ops.linear(torch.zeros(2, 16).cuda(), torch.zeros(4, 32).cuda())
+
+
+def test_sample_stats_and_report_vs_golden_and_oracle():
+    """Reporting tail of test_atk: per-image PIW / variance over the samples, then accuracy, ECE and the per-class
+    means -- against the reference's own functions (report.npz) and the oracle (ECE: torchmetrics semantics)."""
+    from nested_diffusion_amd import ops
+    z = np.load(os.path.join(G, "report.npz"))
+    for n in ("r0", "r1", "r2"):
+        probs = torch.from_numpy(z[n + "_probs"])
+        mv, lab = torch.from_numpy(z[n + "_mv"]), torch.from_numpy(z[n + "_label"])
+        piw, var = ops.sample_stats(probs.cuda())
+        lo, hi = torch.quantile(probs, 0.025, dim=0), torch.quantile(probs, 0.975, dim=0)
+        assert (piw.cpu() - (hi - lo)).abs().max() < 1e-6
+        assert (var.cpu() - probs.var(dim=0)).abs().max() < 1e-6
+        pm = probs.mean(0)
+        rep = ops.report(piw, var, pm.cuda(), mv.cuda(), lab.cuda(), 0.1737, 10)
+        assert abs(float(rep["accuracy"]) - float(ref_cpu.compute_accuracy(mv, lab))) < 1e-7
+        for key, ref in (("piw_correct", z[n + "_piw_c"]), ("piw_incorrect", z[n + "_piw_i"]),
+                         ("var_correct", z[n + "_var_c"]), ("var_incorrect", z[n + "_var_i"])):
+            got = rep[key].numpy()
+            assert np.array_equal(np.isnan(got), np.isnan(ref)), (n, key)
+            assert np.nanmax(np.abs(got - ref), initial=0.0) < 2e-6, (n, key, got, ref)
+        ece = ref_cpu.compute_ece_as_reference(pm, lab, 0.1737)
+        assert abs(float(rep["ece"]) - float(ece)) < 2e-6
+    # quantile interpolation edge cases: S = 1, S = 2, ties
+    for S in (1, 2, 3):
+        p = torch.tensor([0.25, 0.25, 0.75])[:S].reshape(S, 1, 1).repeat(1, 2, 2).contiguous()
+        piw, var = ops.sample_stats(p.cuda())
+        ref = torch.quantile(p, 0.975, dim=0) - torch.quantile(p, 0.025, dim=0)
+        assert (piw.cpu() - ref).abs().max() < 1e-6

@@ -81,6 +81,24 @@ def test_aggregation_bit_exact():
     assert int(z["a1_vote"][0]) == 0          # tie 2:2 -> smallest label
 
 
+def test_report_functions_bit_exact():
+    z = _load("report.npz")
+    for n in ("r0", "r1", "r2"):
+        probs = [torch.from_numpy(p) for p in z[n + "_probs"]]
+        mv, lab = torch.from_numpy(z[n + "_mv"]), torch.from_numpy(z[n + "_label"])
+        pc, pi = ref_cpu.compute_mean_piws_for_class(probs, mv, lab)
+        vc, vi = ref_cpu.calculate_variances(probs, mv, lab)
+        assert np.array_equal(pc.numpy(), z[n + "_piw_c"], equal_nan=True) and np.array_equal(pi.numpy(), z[n + "_piw_i"], equal_nan=True)
+        assert np.array_equal(vc.numpy(), z[n + "_var_c"]) and np.array_equal(vi.numpy(), z[n + "_var_i"])
+    assert np.isnan(z["r2_piw_c"][1]) and z["r2_var_i"][0] == 0.0        # empty selections: NaN PIW, zero variance
+    # calibration error (torchmetrics 0.11.4 semantics, unpinned): hand-checkable case
+    probs = torch.tensor([[0.95, 0.05], [0.55, 0.45], [0.30, 0.70], [0.85, 0.15]])
+    target = torch.tensor([0, 1, 1, 0])
+    # bins (0.9,1.0]: conf .95 acc 1 ; (0.5,0.6]: conf .55 acc 0 ; (0.6,0.7]: conf .70 acc 1 ; (0.8,0.9]: conf .85 acc 1
+    want = (abs(1 - 0.95) + abs(0 - 0.55) + abs(1 - 0.70) + abs(1 - 0.85)) / 4
+    assert abs(float(ref_cpu.multiclass_calibration_error_l1(probs, target, 10)) - want) < 1e-6
+
+
 @pytest.mark.slow
 def test_classifier_full_dims():
     z = _load("classifier_full.npz")

@@ -216,6 +216,26 @@ def gen_aggregation(runner):
     print("aggregation.npz")
 
 
+def gen_report(runner):
+    """compute_mean_piws_for_class / calculate_variances / accuracy of the reference on synthetic per-sample
+    probabilities (what pred_mc holds after compute_ensemble_confidence, quirk Q4)."""
+    g = torch.Generator().manual_seed(11)
+    save = {}
+    for name, S, N, C in (("r0", 100, 64, 2), ("r1", 25, 37, 3), ("r2", 8, 5, 2)):
+        probs = [torch.softmax(torch.randn(N, C, generator=g) * 1.5, dim=1) for _ in range(S)]
+        mv = torch.randint(0, C, (N,), generator=g)
+        label = torch.randint(0, C, (N,), generator=g)
+        if name == "r2":
+            mv = torch.zeros(N, dtype=torch.long); label = torch.zeros(N, dtype=torch.long)   # empty selections -> NaN / 0
+        pc, pi = runner.compute_mean_piws_for_class([p.clone() for p in probs], mv, label)
+        vc, vi = runner.calculate_variances([p.clone() for p in probs], mv, label)
+        save[name + "_probs"] = torch.stack(probs).numpy(); save[name + "_mv"] = mv.numpy(); save[name + "_label"] = label.numpy()
+        save[name + "_piw_c"] = pc.numpy(); save[name + "_piw_i"] = pi.numpy()
+        save[name + "_var_c"] = vc.numpy(); save[name + "_var_i"] = vi.numpy()
+    np.savez_compressed(os.path.join(OUT, "report.npz"), **save)
+    print("report.npz")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-full", action="store_true")
@@ -228,6 +248,7 @@ def main():
     try:
         runner = import_reference_runner()
         gen_aggregation(runner)
+        gen_report(runner)
     except Exception as e:  # ordinary Python error -> recorded, aggregation stays self-pinned
         print("runner import failed:", type(e).__name__, e)
     if not a.skip_full:
