@@ -202,6 +202,23 @@ int nd_sample_stats(const float *probs_dev, float *piw_out_dev, float *var_out_d
 int nd_report(const float *piw_dev, const float *var_dev, const float *prob_mean_dev, const int64_t *vote_dev,
               const int64_t *target_dev, float *out_dev, int N, int C, float temperature, int n_bins, void *stream);
 
+/* ---- input perturbations of the robustness protocol (diffusion/utils.py:272-414; applied at
+ * classification_train_separately.py:726-737).  Images are [B, C, H, W] fp32, contiguous. ------------------- */
+/* add_noise (:272-279): out = x + z * std, z = the randn_like draw (supplied, like the sampler's noise). */
+int nd_img_add_noise(const float *x_dev, const float *z_dev, float *out_dev, size_t n, float std, void *stream);
+/* adjust_brightness (:390-399): out = clamp(x + k, 0, 1). */
+int nd_img_brightness(const float *x_dev, float *out_dev, size_t n, float k, void *stream);
+/* adjust_contrast (:402-414): m = per-image mean; out = clamp(m + (x - m) * k, 0, 1).  mean_ws_dev: B floats. */
+int nd_img_contrast(const float *x_dev, float *out_dev, float *mean_ws_dev, int B, size_t per_image, float k, void *stream);
+/* torch interpolate(mode='bilinear', align_corners=False) [B,C,Hi,Wi] -> [B,C,Ho,Wo]: down_up_sample (:372-387) is two
+ * calls.  With crop_dev != NULL ([B][2] int32 = top, left) the source is the crop_size x crop_size window of each
+ * image: random_crop_and_resize (:282-312; torchvision Resize on tensors = the same interpolate). */
+int nd_img_resize_bilinear(const float *x_dev, float *out_dev, int B, int C, int Hi, int Wi, int Ho, int Wo,
+                           const int32_t *crop_dev, int crop_size, void *stream);
+/* random_cover_new (:315-349): zero n_rects squares of side `side` per image, in place; rects_dev [B][n_rects][2]
+ * int32 = (top, left), chosen on the host with the reference's rejection sampling. */
+int nd_img_cover(float *x_dev, int B, int C, int H, int W, const int32_t *rects_dev, int n_rects, int side, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

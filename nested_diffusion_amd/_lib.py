@@ -77,6 +77,11 @@ SIGNATURES = {
     "nd_softmax_rows": (_i, [_vp, _vp, _i, _i, _vp]),
     "nd_aggregate": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
     "nd_sample_stats": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _f, _vp]),
+    "nd_img_add_noise": (_i, [_vp, _vp, _vp, _sz, _f, _vp]),
+    "nd_img_brightness": (_i, [_vp, _vp, _sz, _f, _vp]),
+    "nd_img_contrast": (_i, [_vp, _vp, _vp, _i, _sz, _f, _vp]),
+    "nd_img_resize_bilinear": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
+    "nd_img_cover": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _vp]),
     "nd_report": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _vp]),
 }
 

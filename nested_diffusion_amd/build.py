@@ -13,7 +13,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libnd_hip.so")
-SOURCES = ["nd_sampler.hip", "nd_ops.hip", "nd_vit.hip"]
+SOURCES = ["nd_sampler.hip", "nd_ops.hip", "nd_vit.hip", "nd_image.hip"]
 HEADERS = [os.path.join(CSRC, "nd_common.hpp"), os.path.join(os.path.dirname(HERE), "include", "nested_diffusion.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 
@@ -50,7 +50,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
             print(r.stderr)
         return obj
 
-    with ThreadPoolExecutor(max_workers=3) as ex:
+    with ThreadPoolExecutor(max_workers=4) as ex:
         objs = list(ex.map(cc, SOURCES))
     r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs], capture_output=True, text=True)
     if r.returncode != 0:

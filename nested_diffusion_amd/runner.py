@@ -155,17 +155,30 @@ class Diffusion(object):
         prob, vote, probs = ops.aggregate(samples, self.temperature, return_probs=True)  # :786, :789
         return {"samples": samples, "vote": vote, "prob": prob, "probs": probs, "yhat": yhat}
 
+    # ---- input perturbations (:726-737), in the reference's order ------------------------------
+    def perturb(self, images_224: torch.Tensor) -> torch.Tensor:
+        from . import perturb as P
+        a = self.args
+        if (getattr(a, "noise_perturbation", 0.0) or 0.0) > 0.0:
+            images_224 = P.add_noise(images_224, a.noise_perturbation)
+        if (getattr(a, "low_resolution", 0) or 0) > 1:
+            images_224 = P.down_up_sample(images_224, a.low_resolution)
+        if (getattr(a, "brightness", 0.0) or 0.0) != 0.0:
+            images_224 = P.adjust_brightness(images_224, a.brightness)
+        if getattr(a, "contrast", 1.0) not in (1.0, None):
+            images_224 = P.adjust_contrast(images_224, a.contrast)
+        covered = getattr(a, "covered", (0.0, 0.0)) or (0.0, 0.0)
+        if covered[0] > 0:
+            images_224 = P.random_cover_new(images_224, covered)
+        if (getattr(a, "crop", 0.0) or 0.0) > 0:
+            images_224 = P.random_crop_and_resize(images_224, a.crop)
+        return images_224
+
     # ---- test loop ----------------------------------------------------------------------------
     def test_atk(self, test_loader=None):
-        """:631-840: the hot path plus the report the reference prints (accuracy, ECE, per-class PIW and variances,
-        :801-838).  Input perturbations / attacks (:726-739) are 'next' rows of SURVEY 8f and raise if requested."""
+        """:631-840: input perturbations (:726-737), the hot path, and the report the reference prints (accuracy, ECE,
+        per-class PIW and variances, :801-838).  Adversarial attacks (:738-739) need ViT gradients and raise."""
         args, config = self.args, self.config
-        for flag, off in (("noise_perturbation", 0.0), ("low_resolution", 0), ("brightness", 0.0), ("crop", 0.0)):
-            v = getattr(args, flag, off) or off
-            if (flag == "low_resolution" and v > 1) or (flag != "low_resolution" and v != off):
-                raise NotImplementedError(f"--{flag}: input perturbations are not part of the accelerated path yet")
-        if getattr(args, "contrast", 1.0) not in (1.0, None):
-            raise NotImplementedError("--contrast: input perturbations are not part of the accelerated path yet")
         if getattr(args, "attack_name", None) not in (None, "None"):
             raise NotImplementedError("adversarial attacks need gradients through the ViT: out of scope")
         if test_loader is None:
@@ -179,6 +192,7 @@ class Diffusion(object):
         n_step_img, t0 = 0, time.time()
         for images_raw, target in test_loader:
             images = images_raw[lo:hi].to(self.device, torch.float32)
+            images = self.perturb(images)                                    # :726-737
             out = self.predict_batch(images)
             # spread of the K*mc per-sample probabilities per image (what the reference keeps in pred_mc, quirk Q4)
             piw, var = ops.sample_stats(out["probs"])

@@ -454,3 +454,49 @@ def compute_ece_as_reference(prob_mc: Tensor, target: Tensor, temperature: float
     """Diffusion.compute_ece as test_atk calls it (:413-423, :812): prob_in defaults to False, so the already
     averaged probabilities go through convert_to_prob once more before the calibration error (quirk kept)."""
     return multiclass_calibration_error_l1(convert_to_prob(prob_mc, temperature), target, 10)
+
+
+# ----------------------------------------------------------------------------
+# input perturbations  (diffusion/utils.py:272-414)
+# ----------------------------------------------------------------------------
+def add_noise(images: Tensor, noise_std: float, z: Tensor) -> Tensor:
+    """utils.py:272-279 with the randn_like draw supplied."""
+    return images + z * noise_std
+
+
+def adjust_brightness(images: Tensor, k: float) -> Tensor:
+    """utils.py:390-399."""
+    return torch.clamp(images + k, 0, 1)
+
+
+def adjust_contrast(images: Tensor, k: float) -> Tensor:
+    """utils.py:402-414."""
+    means = images.mean(dim=[1, 2, 3], keepdim=True)
+    return torch.clamp(means + (images - means) * k, 0, 1)
+
+
+def down_up_sample(images: Tensor, k: int) -> Tensor:
+    """utils.py:372-387."""
+    H, W = images.shape[-2:]
+    down = F.interpolate(images, size=(H // k, W // k), mode="bilinear", align_corners=False)
+    return F.interpolate(down, size=(H, W), mode="bilinear", align_corners=False)
+
+
+def cover_regions(images: Tensor, rects, side: int) -> Tensor:
+    """The pixel part of random_cover_new (utils.py:345-347) for given (top, left) corners per image."""
+    out = images.clone()
+    for b, rs in enumerate(rects):
+        for top, left in rs:
+            out[b, :, top:top + side, left:left + side] = 0
+    return out
+
+
+def crop_and_resize(images: Tensor, corners, crop: int) -> Tensor:
+    """The pixel part of random_crop_and_resize (utils.py:292-300): crop, then torchvision 0.11 tensor Resize =
+    interpolate(bilinear, align_corners=False) (torchvision absent here: that equivalence is from its published source)."""
+    H, W = images.shape[-2:]
+    outs = []
+    for b, (top, left) in enumerate(corners):
+        c = images[b:b + 1, :, top:top + crop, left:left + crop]
+        outs.append(F.interpolate(c, size=(H, W), mode="bilinear", align_corners=False)[0])
+    return torch.stack(outs)

@@ -66,6 +66,15 @@ def test_main_test_path_end_to_end(tmp_path, capsys, monkeypatch):
     assert "Testing procedure finished" in txt and "Traceback" not in txt, txt
     saved = yaml.unsafe_load(open(os.path.join(log, "config.yml")))
     assert saved.diffusion.timesteps == T                                   # --timesteps override (main.py:192-193)
+    # the perturbation flags of test.sh drive the HIP perturbation ops (reference order, :726-737)
+    argv2 = [a for a in argv]
+    for flag, val in (("--noise_perturbation", "0.1"), ("--low_resolution", "2"), ("--brightness", "0.2"), ("--contrast", "1.5"), ("--crop", "0.25")):
+        argv2[argv2.index(flag) + 1] = val
+    argv2 += ["--covered", "0.05", "2"]
+    argv2[argv2.index("--doc") + 1] = "perturbed"
+    assert nd_main.main(argv2) == 0
+    txt2 = open(os.path.join(str(tmp_path), "results", "logs", "perturbed", "split_0", "stdout.txt")).read()
+    assert "Testing procedure finished" in txt2 and "Traceback" not in txt2, txt2
 
 
 def test_main_swallows_errors_like_the_reference(tmp_path, capsys):
@@ -73,7 +82,7 @@ def test_main_swallows_errors_like_the_reference(tmp_path, capsys):
     from nested_diffusion_amd import main as nd_main
     ypath, *_ = _write_run(str(tmp_path))
     argv = ["--test", "--loss", "card_onehot_conditional", "--config", ypath, "--exp", os.path.join(str(tmp_path), "r"), "--doc", "d",
-            "--ni", "--preprocess", "grayscaled", "--timesteps", "6", "--brightness", "0.3", "--synthetic_batches", "1"]
+            "--ni", "--preprocess", "grayscaled", "--timesteps", "6", "--attack_name", "FGSM", "--eps", "0.03", "--synthetic_batches", "1"]
     assert nd_main.main(argv) == 0
     txt = open(os.path.join(str(tmp_path), "r", "logs", "d", "split_0", "stdout.txt")).read()
-    assert "NotImplementedError" in txt and "--brightness" in txt
+    assert "NotImplementedError" in txt and "attacks" in txt

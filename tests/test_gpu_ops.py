@@ -157,3 +157,36 @@ def test_sample_stats_and_report_vs_golden_and_oracle():
         piw, var = ops.sample_stats(p.cuda())
         ref = torch.quantile(p, 0.975, dim=0) - torch.quantile(p, 0.025, dim=0)
         assert (piw.cpu() - ref).abs().max() < 1e-6
+
+
+def test_perturbation_ops_vs_reference_goldens():
+    """diffusion/utils.py perturbations: HIP kernels against outputs of the reference's own functions (perturb.npz);
+    crop-and-resize against the oracle (torchvision's tensor Resize = bilinear interpolate, unpinned)."""
+    import random
+    from nested_diffusion_amd import perturb as P
+    z = np.load(os.path.join(G, "perturb.npz"))
+    x = torch.from_numpy(z["x"]).cuda()
+    def close(got, ref, tol=2e-7):
+        assert np.abs(got.cpu().numpy() - ref).max() <= tol, np.abs(got.cpu().numpy() - ref).max()
+    close(P.add_noise(x, 0.3, z=torch.from_numpy(z["z"]).cuda()), z["noise_0p3"], 0)          # exact
+    close(P.adjust_brightness(x, 0.4), z["bright_p0p4"], 0)
+    close(P.adjust_brightness(x, -0.3), z["bright_m0p3"], 0)
+    close(P.adjust_contrast(x, 1.7), z["contrast_1p7"], 5e-7)        # the per-image mean is a differently ordered sum
+    close(P.adjust_contrast(x, 0.4), z["contrast_0p4"], 5e-7)
+    close(P.down_up_sample(x, 2), z["downup_2"], 3e-7)
+    close(P.down_up_sample(x, 3), z["downup_3"], 3e-7)
+    random.seed(9)
+    close(P.random_cover_new(x, (0.05, 2)), z["cover_0p05_2"], 0)    # same python-random picks as the reference
+    corners = [(1, 0), (3, 2), (0, 4)]
+    got = P.random_crop_and_resize(x, 0.25, corners=corners)
+    ref = ref_cpu.crop_and_resize(x.cpu(), corners, int(20 * 0.75))
+    close(got, ref.numpy(), 3e-7)
+    torch.manual_seed(3)
+    out = P.random_crop_and_resize(x, 0.25)
+    assert out.shape == x.shape and torch.isfinite(out).all()
+    # config-size image batch: shapes / ranges
+    big = torch.rand(4, 3, 224, 224, device="cuda")
+    assert float(P.adjust_contrast(big, 2.0).max()) <= 1.0 and float(P.adjust_brightness(big, -0.5).min()) >= 0.0
+    d = P.down_up_sample(big, 4)
+    assert d.shape == big.shape
+    assert (d.cpu() - ref_cpu.down_up_sample(big.cpu(), 4)).abs().max() < 3e-7

@@ -99,6 +99,23 @@ def test_report_functions_bit_exact():
     assert abs(float(ref_cpu.multiclass_calibration_error_l1(probs, target, 10)) - want) < 1e-6
 
 
+def test_perturbations_bit_exact():
+    import random
+    z = _load("perturb.npz")
+    x = torch.from_numpy(z["x"])
+    assert np.array_equal(ref_cpu.add_noise(x, 0.3, torch.from_numpy(z["z"])).numpy(), z["noise_0p3"])
+    assert np.array_equal(ref_cpu.adjust_brightness(x, 0.4).numpy(), z["bright_p0p4"])
+    assert np.array_equal(ref_cpu.adjust_brightness(x, -0.3).numpy(), z["bright_m0p3"])
+    assert np.array_equal(ref_cpu.adjust_contrast(x, 1.7).numpy(), z["contrast_1p7"])
+    assert np.array_equal(ref_cpu.adjust_contrast(x, 0.4).numpy(), z["contrast_0p4"])
+    assert np.array_equal(ref_cpu.down_up_sample(x, 2).numpy(), z["downup_2"])
+    assert np.array_equal(ref_cpu.down_up_sample(x, 3).numpy(), z["downup_3"])
+    from nested_diffusion_amd.perturb import pick_cover_regions          # host logic: the reference's rejection sampling
+    random.seed(9)
+    side, rects = pick_cover_regions(3, 24, 20, 0.05, 2)
+    assert np.array_equal(ref_cpu.cover_regions(x, rects, side).numpy(), z["cover_0p05_2"])
+
+
 @pytest.mark.slow
 def test_classifier_full_dims():
     z = _load("classifier_full.npz")

@@ -236,6 +236,27 @@ def gen_report(runner):
     print("report.npz")
 
 
+def gen_perturb(runner):
+    """add_noise / adjust_brightness / adjust_contrast / down_up_sample / random_cover_new of the reference
+    (diffusion/utils.py, star-imported by the runner module) on small images.  random_crop_and_resize needs
+    torchvision's Resize and is not runnable here."""
+    import random as pyrandom
+    g = torch.Generator().manual_seed(21)
+    x = torch.rand(3, 3, 24, 20, generator=g)
+    save = {"x": x.numpy()}
+    torch.manual_seed(5)
+    z = torch.randn_like(x)
+    torch.manual_seed(5)
+    save["z"] = z.numpy(); save["noise_0p3"] = runner.add_noise(x, 0.3).numpy()
+    save["bright_p0p4"] = runner.adjust_brightness(x, 0.4).numpy(); save["bright_m0p3"] = runner.adjust_brightness(x, -0.3).numpy()
+    save["contrast_1p7"] = runner.adjust_contrast(x, 1.7).numpy(); save["contrast_0p4"] = runner.adjust_contrast(x, 0.4).numpy()
+    save["downup_2"] = runner.down_up_sample(x, 2).numpy(); save["downup_3"] = runner.down_up_sample(x, 3).numpy()
+    pyrandom.seed(9)
+    save["cover_0p05_2"] = runner.random_cover_new(x, (0.05, 2)).numpy()
+    np.savez_compressed(os.path.join(OUT, "perturb.npz"), **save)
+    print("perturb.npz")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-full", action="store_true")
@@ -249,6 +270,7 @@ def main():
         runner = import_reference_runner()
         gen_aggregation(runner)
         gen_report(runner)
+        gen_perturb(runner)
     except Exception as e:  # ordinary Python error -> recorded, aggregation stays self-pinned
         print("runner import failed:", type(e).__name__, e)
     if not a.skip_full:
