@@ -5,7 +5,7 @@
 
 Same flags, YAML keys and checkpoint layout as the reference (main.py:16-161, 166-296, 299-380;
 canonical invocation testing_scripts/test.sh:24).  Only `--test` with loss card_onehot_conditional and
-aux_cls.arch == 'sevit' (the shipped configs) is implemented; training / calibration / sampling flags are
+aux_cls.arch == 'sevit' (the shipped configs) and `--calib` are implemented; training / sampling flags are
 parsed for compatibility and rejected at dispatch.  Additions: --synthetic_batches, --mc_trials.
 Multi-GPU: launch with `python -m torch.distributed.run --nproc-per-node N -m nested_diffusion_amd.main ...`.
 """
@@ -161,7 +161,10 @@ def main(argv=None) -> int:
             runner.test_atk()
             procedure = "Testing"
         elif args.calib:
-            raise NotImplementedError("--calib (test_calibrate) is outside the accelerated hot path (SURVEY 8f-3)")
+            from scipy.optimize import minimize                      # main.py:356-361
+            res = minimize(runner.test_calibrate, 0.2555, method='Nelder-Mead', options={'xatol': 1e-4, 'fatol': 1e-5, 'disp': True})
+            print("Optimal t value: {:.4f}".format(res.x[0]))
+            procedure = "Testing"
         else:
             raise NotImplementedError("training is outside the accelerated hot path")
         logging.info("\n{} procedure finished. It took {:.4f} minutes.\n\n\n".format(procedure, (time.time() - start_time) / 60))

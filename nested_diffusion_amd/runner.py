@@ -155,6 +155,42 @@ class Diffusion(object):
         prob, vote, probs = ops.aggregate(samples, self.temperature, return_probs=True)  # :786, :789
         return {"samples": samples, "vote": vote, "prob": prob, "probs": probs, "yhat": yhat}
 
+    # ---- temperature calibration (:449-629, driven by main.py:356-361) ---------------------------
+    def test_calibrate(self, temp=None, test_loader=None):
+        """ECE of the ensemble at scaling temperature `temp` on the validation set (:449-629).  The reference
+        re-runs the whole sampler for every temperature the Nelder-Mead search tries although the samples y_0 do not
+        depend on it; here the raw samples are drawn once and cached (set ND_CALIB_RESAMPLE=1 for the as-written,
+        stochastic objective), so each further evaluation is one aggregation + one calibration-error kernel."""
+        if temp is not None:
+            self.temperature = float(temp[0] if hasattr(temp, "__len__") else temp)
+        resample = bool(int(os.environ.get("ND_CALIB_RESAMPLE", "0")))
+        if resample or getattr(self, "_calib_cache", None) is None:
+            if test_loader is None:
+                from .data import get_test_loader
+                test_loader = get_test_loader(self.args, self.config)
+            rank, world = nd_dist.rank_world()
+            B = self.config.testing.batch_size
+            lo, hi = nd_dist.shard_bounds(B, rank, world)
+            if self.engine is None:
+                self.load_noise_estimators(max_batch=max(hi - lo, 1))
+            samples, targets = [], []
+            for images_raw, target in test_loader:
+                images = self.perturb(images_raw[lo:hi].to(self.device, torch.float32))
+                out = self.predict_batch(images)
+                S = out["samples"].shape[0]
+                flat = out["samples"].permute(1, 0, 2).reshape(hi - lo, -1).contiguous()      # [B_local, S*C]
+                flat = nd_dist.all_gather_rows(flat, B, world)
+                samples.append(flat.reshape(B, S, -1).permute(1, 0, 2).contiguous())
+                targets.append(target.to(self.device))
+            self._calib_cache = (torch.cat(samples, dim=1).contiguous(), torch.cat(targets))
+        samples, targets = self._calib_cache
+        prob, vote, _ = ops.aggregate(samples, self.temperature)              # compute_ensemble_confidence (:612)
+        rep = ops.report(prob, prob, prob, vote, targets, self.temperature, n_bins=10)   # compute_ece (:619)
+        ece = float(rep["ece"])
+        print(f"Ours ECE: {ece} \n")
+        logging.info(f"Ours ECE: {ece} \n")
+        return ece
+
     # ---- input perturbations (:726-737), in the reference's order ------------------------------
     def perturb(self, images_224: torch.Tensor) -> torch.Tensor:
         from . import perturb as P

@@ -86,3 +86,20 @@ def test_main_swallows_errors_like_the_reference(tmp_path, capsys):
     assert nd_main.main(argv) == 0
     txt = open(os.path.join(str(tmp_path), "r", "logs", "d", "split_0", "stdout.txt")).read()
     assert "NotImplementedError" in txt and "attacks" in txt
+
+
+def test_calib_path_nelder_mead(tmp_path, capsys, monkeypatch):
+    """`--calib`: scipy Nelder-Mead over the scaling temperature around test_calibrate (main.py:356-361), samples cached."""
+    from nested_diffusion_amd import main as nd_main
+    from nested_diffusion_amd import mapping
+    import nested_diffusion_amd.runner as runner_mod
+    ypath, vp, mlps, members, dims = _write_run(str(tmp_path), T=5, K=5, B=8)
+    orig = mapping.load_conditioner
+    monkeypatch.setattr(runner_mod, "load_conditioner", lambda path, ds, device="cuda", num_heads=12: orig(path, ds, device, dims["heads"]))
+    argv = ["--calib", "--loss", "card_onehot_conditional", "--config", ypath, "--exp", os.path.join(str(tmp_path), "c"), "--doc", "cal",
+            "--ni", "--preprocess", "grayscaled", "--timesteps", "5", "--seed", "3", "--synthetic_batches", "2", "--mc_trials", "2"]
+    assert nd_main.main(argv) == 0
+    out = capsys.readouterr().out
+    assert "Optimal t value:" in out and out.count("Ours ECE:") >= 10, out
+    txt = open(os.path.join(str(tmp_path), "c", "logs", "cal", "split_0", "stdout.txt")).read()
+    assert "Traceback" not in txt, txt

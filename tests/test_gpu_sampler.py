@@ -216,3 +216,25 @@ def test_large_m_row_groups(B, mc, F_, C_):
     eps = eng.eps_theta(1, yy, yhat[1], 2, mc=mc).cpu()
     ref = ref_cpu.trunk(ps[1], ref_cpu.encoder_x(ps[1], x).repeat(mc, 1), yy, torch.tensor([2]), yhat[1].repeat(mc, 1))
     assert (eps - ref).abs().max() < 5e-5 * max(1.0, ref.abs().max())
+
+
+@pytest.mark.parametrize("T,B,C_", [(1, 2, 2), (2, 1, 2), (3, 5, 1), (4, 1, 5)])
+def test_edge_sizes(T, B, C_):
+    """Smallest loops (T = 1: no reverse step, only the t = 0 reparameterisation), single image, one and five classes."""
+    from nested_diffusion_amd.engine import EnsembleEngine
+    D, H, Fd = 32, 16, 32
+    p = ref_cpu.init_cond_model_params(D, H, Fd, C_, T, True, seed=T * 10 + B)
+    eng = EnsembleEngine(C_, D, H, Fd, T, n_members=1, max_batch=B)
+    eng.load_member(0, p)
+    alphas, omabs = ref_cpu.schedule_tables("linear", max(T, 2), 1e-4, 0.02)
+    alphas, omabs = alphas[:T].contiguous(), omabs[:T].contiguous()
+    eng.set_schedule(alphas, omabs)
+    g = torch.Generator().manual_seed(T)
+    x = torch.rand(B, D, generator=g)
+    yhat = torch.softmax(torch.randn(B, C_, generator=g), -1)
+    noise = torch.randn(T, B, C_, generator=g)
+    eng.encode(x)
+    seq = eng.sample(yhat[None].cuda(), yhat[None].cuda(), noise[None].cuda(), return_seq=True)[0].cpu()
+    ref = torch.stack(ref_cpu.p_sample_loop(p, x, yhat, yhat, T, alphas, omabs, noise, only_last_sample=False))
+    assert seq.shape == ref.shape == (T + 1, B, C_)
+    assert (seq - ref).abs().max() < 5e-5 * max(1.0, ref.abs().max())
