@@ -9,7 +9,7 @@ library is missing.
 
 Pinning: the sampler, the eps_theta network, the schedule tables, the mapping MLP and
 the aggregation functions are pinned against outputs of the reference itself, imported
-in the build container by ``tools/gen_golden.py`` (fixtures under ``tests/golden/``,
+in the build container by ``tests/golden/gen_golden.py`` (fixtures under ``tests/golden/``,
 checked by ``tests/test_oracle_golden.py``).  The ViT prefix (timm 0.4.12, third-party,
 source absent from /root/reference and not installed) is restated from timm 0.4.12's
 published ``vision_transformer.py`` semantics: PARITY UNPINNED for that one piece.

@@ -15,7 +15,7 @@ box).  The reference modules are imported unmodified from /root/reference:
   same kind of placeholder for absent, unused third-party imports.
 
 Only arrays (inputs + expected outputs) and seeds are written; no reference source text.
-Usage:  python tools/gen_golden.py [--skip-full]
+Usage:  python tests/golden/gen_golden.py [--skip-full]
 """
 from __future__ import annotations
 
@@ -27,7 +27,7 @@ import types
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 REF = "/root/reference"
 OUT = os.path.join(ROOT, "tests", "golden")
 sys.path.insert(0, ROOT)

@@ -1,5 +1,5 @@
 """The oracle (oracle/ref_cpu.py) against fixtures produced by running the reference itself
-(tools/gen_golden.py).  CPU only.  Tolerances: bit-exact where the oracle performs the same
+(tests/golden/gen_golden.py).  CPU only.  Tolerances: bit-exact where the oracle performs the same
 torch ops in the same order (schedule, sampler, eps_theta, aggregation)."""
 import os
 
