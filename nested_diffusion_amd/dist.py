@@ -57,10 +57,14 @@ def all_gather_rows(local: torch.Tensor, n_total: int, world: int = None) -> tor
         return local
     q, r = divmod(n_total, world)
     widest = q + (1 if r else 0)
-    pad = torch.zeros((widest,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    pad[: local.shape[0]] = local
-    out = torch.empty((world * widest,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dev = local.device
+    # RCCL gathers device tensors directly; gloo (CPU rehearsal of the N>1 path) is staged through the host
+    stage = torch.device("cpu") if (td.get_backend() == "gloo" and local.is_cuda) else dev
+    pad = torch.zeros((widest,) + tuple(local.shape[1:]), dtype=local.dtype, device=stage)
+    pad[: local.shape[0]] = local.to(stage)
+    out = torch.empty((world * widest,) + tuple(local.shape[1:]), dtype=local.dtype, device=stage)
     td.all_gather_into_tensor(out, pad)
+    out = out.to(dev)
     if r == 0:
         return out
     pieces = []

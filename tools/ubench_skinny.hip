@@ -281,7 +281,7 @@ void launch2(P p, int G, hipStream_t st) {
 // workgroup; a wave keeps NF W fragments + MT x fragments per chunk in registers, so x is loaded once per NF
 // W fragments (L1-miss traffic = W * (1 + MT/NF)).  A workgroup whose range crosses a member boundary loads
 // the x of its first and of its last member ("A" and "B"; identical addresses -> L1 hit when uniform).
-template <int MT, int NF, int WAVES, int U, bool NT, int ABL = 0>
+template <int MT, int NF, int WAVES, int U, bool NT, int ABL = 0, int ROT = 0>
 __global__ __launch_bounds__(WAVES * 64) void k_var3(P p, int G) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int K = p.K, N = p.N, M = p.M;
@@ -330,9 +330,12 @@ __global__ __launch_bounds__(WAVES * 64) void k_var3(P p, int G) {
             for (int mt = 0; mt < MT; ++mt) x[u][mt] = *reinterpret_cast<const float4*>(xb[mt] + ((size_t)grp * U + u) * 256);
     };
     if (uniform) {
-        if (ngw > 0) { LDW(wc, min(wave, glast)); LDX(xc, xA, min(wave, glast)); }
+        // ROT: rotate this workgroup's k order so that workgroups are at different offsets of their fragments
+        const int rot = ROT == 0 ? 0 : (ROT == 1 ? (int)((blockIdx.x * 7u) % (unsigned)max(ngw, 1)) : (int)((blockIdx.x * 37u + blockIdx.x / 8u) % (unsigned)max(ngw, 1)));
+        auto G_OF = [&](int i) { int ii = i + rot; if (ii >= ngw) ii -= ngw; return min(wave + ii * WAVES, glast); };
+        if (ngw > 0) { LDW(wc, G_OF(0)); LDX(xc, xA, G_OF(0)); }
         for (int i = 0; i < ngw; ++i) {
-            const int gn = min(wave + (i + 1) * WAVES, glast);
+            const int gn = G_OF(i + 1 < ngw ? i + 1 : i);
             LDW(wn, gn);
             if (ABL != 2) LDX(xn, xA, gn);
 #pragma unroll
@@ -401,11 +404,11 @@ __global__ __launch_bounds__(WAVES * 64) void k_var3(P p, int G) {
     }
 }
 
-template <int MT, int NF, int WAVES, int U, bool NT, int ABL = 0>
+template <int MT, int NF, int WAVES, int U, bool NT, int ABL = 0, int ROT = 0>
 void launch3(P p, int G, hipStream_t st) {
     const int total = G * (p.N / 16);
     dim3 grid((total + NF - 1) / NF, 1, 1);
-    hipLaunchKernelGGL((k_var3<MT, NF, WAVES, U, NT, ABL>), grid, dim3(WAVES * 64), 0, st, p, G);
+    hipLaunchKernelGGL((k_var3<MT, NF, WAVES, U, NT, ABL, ROT>), grid, dim3(WAVES * 64), 0, st, p, G);
 }
 
 // Variant family 4: as family 3 (uniform workgroups only: benchmark G*N/16 divisible by NF), but the weight
@@ -586,6 +589,11 @@ int main(int argc, char** argv) {
         {"r2 NF4 W12 3-stage nt (G=4)  ", launch4<2, 4, 12, true>},
         {"r3 NF4 W8 3-stage nt (G=4)   ", launch4<2, 4, 8, true>},
         {"r4 NF4 W16 U1 2-stage (G=4)  ", launch3<2, 4, 16, 1, true>},
+        {"t0 NF5 W16 U1 nt rot0        ", launch3<2, 5, 16, 1, true, 0, 0>},
+        {"t1 NF5 W16 U1 nt rot*7       ", launch3<2, 5, 16, 1, true, 0, 1>},
+        {"t2 NF5 W16 U1 nt rot*37      ", launch3<2, 5, 16, 1, true, 0, 2>},
+        {"t3 NF5 W16 U1 loads-only rot ", launch3<2, 5, 16, 1, true, 1, 1>},
+        {"t4 NF5 W16 U1 W-only rot     ", launch3<2, 5, 16, 1, true, 2, 1>},
         {"q1 NF5 W16 U1 nt loads only  ", launch3<2, 5, 16, 1, true, 1>},
         {"q2 NF5 W16 U1 nt W only      ", launch3<2, 5, 16, 1, true, 2>},
         {"q3 NF5 W16 U1 nt full (=p4)  ", launch3<2, 5, 16, 1, true, 0>},
@@ -649,7 +657,7 @@ int main(int argc, char** argv) {
                 CK(hipMemcpy(hout.data(), out, osz * 4, hipMemcpyDeviceToHost));
                 double err = 0, mx = 0;
                 for (size_t i = 0; i < osz; ++i) { err = std::max(err, (double)fabsf(hout[i] - href[i])); mx = std::max(mx, (double)fabsf(href[i])); }
-                printf("check %-32s max|d| = %.3e (max|ref| %.3e) %s\n", vars[v].name, err, mx, err <= 1e-4 * mx ? "ok" : ((vars[v].name[0]=='a' || vars[v].name[0]=='q' || vars[v].name[0]=='r' || vars[v].name[0]=='L') ? "(ablation)" : "MISMATCH"));
+                printf("check %-32s max|d| = %.3e (max|ref| %.3e) %s\n", vars[v].name, err, mx, err <= 1e-4 * mx ? "ok" : ((vars[v].name[0]=='a' || vars[v].name[0]=='q' || vars[v].name[0]=='r' || vars[v].name[0]=='L' || (vars[v].name[0]=='t' && vars[v].name[1]>='3')) ? "(ablation)" : "MISMATCH"));
                 CK(hipMemset(out, 0, osz * 4));
             }
         }
