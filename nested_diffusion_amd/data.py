@@ -1,7 +1,9 @@
-"""Test-set loader.  Disk datasets (torchvision ImageFolder + Grayscale/Resize/ToTensor,
-dataset_helper/chest_x_ray_dataset.py) are a 'next' row of SURVEY 8f; the accelerated path ships a
-synthetic loader of the same tensor contract: batches (images [B,3,224,224] float32 in [0,1), target [B])."""
+"""Test-set loaders: the reference's disk layout (ImageFolder + Grayscale/Resize/ToTensor,
+dataset_helper/chest_x_ray_dataset.py; host-side decode with PIL, as torchvision does) and a synthetic loader
+of the same tensor contract: batches (images [B,3,224,224] float32, target [B] int64)."""
 from __future__ import annotations
+
+import os
 
 import torch
 
@@ -20,6 +22,70 @@ class SyntheticLoader:
                    torch.randint(0, self.C, (self.B,), generator=g))
 
 
+IMG_EXTENSIONS = (".jpg", ".jpeg", ".png", ".ppm", ".bmp", ".pgm", ".tif", ".tiff", ".webp")   # torchvision.datasets.folder
+PRECAL = {"ChestXRay": ((0.5094, 0.5234, 0.5289), (0.2189, 0.2225, 0.2244)),          # chest_x_ray_dataset.py:73-74
+          "ISICSkinCancer": ((0.7187, 0.5684, 0.5464), (0.1212, 0.1325, 0.1434))}      # :139-140
+
+
+class ImageFolderDataset(torch.utils.data.Dataset):
+    """torchvision.datasets.ImageFolder semantics (classes = sorted sub-directories, samples sorted by path, RGB
+    loader) followed by the reference's test-time transforms (dataset_helper/chest_x_ray_dataset.py:31-51, 76-96):
+      grayscaled:   Grayscale(num_output_channels=3) -> Resize((224, 224)) -> ToTensor
+      standardized: Resize((224, 224)) -> ToTensor -> Normalize(pre-calculated mean, std)
+    written with the PIL calls torchvision makes for PIL inputs (L conversion, BILINEAR resize, /255)."""
+
+    def __init__(self, root: str, dataset_name: str, preprocess: str, image_size=(224, 224)):
+        from PIL import Image  # noqa: F401  (fail early if absent)
+        if not os.path.isdir(root):
+            raise FileNotFoundError(f"dataset directory not found: {root}")
+        if preprocess not in ("grayscaled", "standardized"):
+            raise ValueError("Invalid preprocess type")
+        if dataset_name not in PRECAL:
+            raise ValueError("Dataset name is not valid")
+        self.classes = sorted(e.name for e in os.scandir(root) if e.is_dir())
+        if not self.classes:
+            raise FileNotFoundError(f"Couldn't find any class folder in {root}.")
+        self.class_to_idx = {c: i for i, c in enumerate(self.classes)}
+        self.samples = []
+        for c in self.classes:
+            for d, _, files in sorted(os.walk(os.path.join(root, c), followlinks=True)):
+                for f in sorted(files):
+                    if f.lower().endswith(IMG_EXTENSIONS):
+                        self.samples.append((os.path.join(d, f), self.class_to_idx[c]))
+        self.preprocess, self.size = preprocess, tuple(image_size)
+        self.mean, self.std = (torch.tensor(v).view(3, 1, 1) for v in PRECAL[dataset_name])
+
+    def __len__(self):
+        return len(self.samples)
+
+    def __getitem__(self, i):
+        import numpy as np
+        from PIL import Image
+        path, target = self.samples[i]
+        with open(path, "rb") as f:
+            img = Image.open(f).convert("RGB")                                  # default_loader / pil_loader
+        if self.preprocess == "grayscaled":
+            g = np.array(img.convert("L"), dtype=np.uint8)                      # F.to_grayscale(img, 3)
+            img = Image.fromarray(np.dstack([g, g, g]), "RGB")
+        img = img.resize(self.size[::-1], Image.BILINEAR)                       # Resize((h, w)) on a PIL image
+        x = torch.from_numpy(np.array(img, dtype=np.uint8)).permute(2, 0, 1).contiguous().float().div(255)   # ToTensor
+        if self.preprocess == "standardized":
+            x = (x - self.mean) / self.std                                      # Normalize
+        return x, target
+
+
+def get_dataset(args, config):
+    """The ChestXRay / ISICSkinCancer (+ *Validate) branches of diffusion/utils.py:146-164: returns the split the
+    test / calibration loop iterates (testing, or validation for the *Validate names)."""
+    name = config.data.dataset
+    base = {"ChestXRay": "ChestXRay", "ISICSkinCancer": "ISICSkinCancer", "ChestXRayValidate": "ChestXRay",
+            "ISICSkinCancerValidate": "ISICSkinCancer"}.get(name)
+    if base is None:
+        raise NotImplementedError(f"dataset '{name}' is outside the accelerated path")
+    split = "validation" if name.endswith("Validate") else "testing"
+    return ImageFolderDataset(os.path.join(config.data.dataroot, split), base, args.preprocess)
+
+
 def get_test_loader(args, config):
     n = int(getattr(args, "synthetic_batches", 0) or 0)
     if n > 0:
@@ -27,6 +93,6 @@ def get_test_loader(args, config):
         if 3 * size * size != config.model.data_dim:
             raise ValueError(f"model.data_dim={config.model.data_dim} is not 3 x S x S")
         return SyntheticLoader(n, config.testing.batch_size, config.data.num_classes, seed=getattr(args, "seed", 0) or 0, size=size)
-    raise NotImplementedError(
-        "disk datasets need torchvision's ImageFolder pipeline, which is outside the accelerated hot path; "
-        "run with --synthetic_batches N (see INTEGRATION.md for wiring the reference's DataLoader in)")
+    # classification_train_separately.py:674-681: batch_size from the config, no shuffle, drop_last (quirk Q12)
+    return torch.utils.data.DataLoader(get_dataset(args, config), batch_size=config.testing.batch_size, shuffle=False,
+                                       num_workers=int(getattr(config.data, "num_workers", 0) or 0), drop_last=True)

@@ -128,9 +128,51 @@ def test_synthetic_loader_contract():
     assert float(batches[0][0].min()) >= 0.0 and float(batches[0][0].max()) < 1.0
     again = list(SyntheticLoader(2, 3, 2, seed=5, size=32))
     assert torch.equal(batches[1][0], again[1][0])
-    with pytest.raises(NotImplementedError):
-        get_test_loader(argparse.Namespace(synthetic_batches=0), None)
     cfg = argparse.Namespace(model=argparse.Namespace(data_dim=3 * 32 * 32), testing=argparse.Namespace(batch_size=2),
                              data=argparse.Namespace(num_classes=2))
     x, y = next(iter(get_test_loader(argparse.Namespace(synthetic_batches=1, seed=3), cfg)))
     assert x.shape == (2, 3, 32, 32)
+
+
+def test_image_folder_pipeline(tmp_path):
+    """ImageFolder ordering + Grayscale(3)/Resize(224)/ToTensor, drop_last loader (dataset_helper/chest_x_ray_dataset.py,
+    classification_train_separately.py:674-681) on a tiny PNG/JPEG tree."""
+    import numpy as np
+    from PIL import Image
+    from nested_diffusion_amd.data import get_test_loader, ImageFolderDataset
+    rng = np.random.default_rng(0)
+    root = tmp_path / "data"
+    for split in ("testing", "validation"):
+        for cls, n in (("PNEUMONIA", 3), ("NORMAL", 2)):
+            d = root / split / cls
+            d.mkdir(parents=True)
+            for i in range(n):
+                arr = rng.integers(0, 255, size=(37 + i, 53, 3), dtype=np.uint8)
+                Image.fromarray(arr, "RGB").save(d / f"img_{i}.png")
+        (root / split / "NORMAL" / "notes.txt").write_text("not an image")
+    args = argparse.Namespace(synthetic_batches=0, preprocess="grayscaled", seed=0)
+    cfg = argparse.Namespace(data=argparse.Namespace(dataset="ChestXRay", dataroot=str(root), num_workers=0, num_classes=2),
+                             testing=argparse.Namespace(batch_size=2), model=argparse.Namespace(data_dim=150528))
+    loader = get_test_loader(args, cfg)
+    batches = list(loader)
+    assert len(batches) == 2                                      # 5 images, batch 2, drop_last -> 2 batches
+    x, y = batches[0]
+    assert x.shape == (2, 3, 224, 224) and x.dtype == torch.float32 and y.tolist() == [0, 0]   # NORMAL sorts first
+    assert torch.equal(x[:, 0], x[:, 1]) and torch.equal(x[:, 1], x[:, 2])                     # grayscale replicated
+    assert 0.0 <= float(x.min()) and float(x.max()) <= 1.0
+    # value check against the PIL calls written out by hand
+    ds = loader.dataset
+    assert ds.classes == ["NORMAL", "PNEUMONIA"] and len(ds) == 5
+    img = Image.open(ds.samples[0][0]).convert("RGB").convert("L")
+    g = np.array(img)
+    ref = np.array(Image.fromarray(np.dstack([g, g, g]), "RGB").resize((224, 224), Image.BILINEAR)).astype(np.float32) / 255
+    assert np.array_equal(ds[0][0].numpy(), ref.transpose(2, 0, 1))
+    # validation split + standardized preprocess
+    cfg.data.dataset = "ChestXRayValidate"; args.preprocess = "standardized"
+    xv, _ = next(iter(get_test_loader(args, cfg)))
+    assert xv.shape == (2, 3, 224, 224) and float(xv.min()) < 0.0
+    with pytest.raises(FileNotFoundError):
+        ImageFolderDataset(str(root / "nope"), "ChestXRay", "grayscaled")
+    cfg.data.dataset = "MNIST"
+    with pytest.raises(NotImplementedError):
+        get_test_loader(args, cfg)
