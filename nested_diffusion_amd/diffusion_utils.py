@@ -12,34 +12,30 @@ from typing import List, Optional, Union
 import torch
 
 
+def _cosine_alpha_bar(u: float, s: float = 0.008) -> float:
+    return math.cos((u + s) / (1 + s) * math.pi / 2) ** 2
+
+
 def make_beta_schedule(schedule="linear", num_timesteps=1000, start=1e-5, end=1e-2):
-    """diffusion_utils.py:5-28.  Init-time host table (T floats), built with the same torch ops as
-    the reference so the tables are bit-identical (pinned by tests/golden/schedule.npz)."""
+    """Noise schedule beta_1..beta_T (reference: diffusion_utils.py:5-28; same names, same fp32 torch ops per branch, so
+    the tables are bit-identical -- pinned by tests/golden/schedule.npz).  Init-time host table of T floats."""
+    T = num_timesteps
     if schedule == "linear":
-        betas = torch.linspace(start, end, num_timesteps)
-    elif schedule == "const":
-        betas = end * torch.ones(num_timesteps)
-    elif schedule == "quad":
-        betas = torch.linspace(start ** 0.5, end ** 0.5, num_timesteps) ** 2
-    elif schedule == "jsd":
-        betas = 1.0 / torch.linspace(num_timesteps, 1, num_timesteps)
-    elif schedule == "sigmoid":
-        betas = torch.linspace(-6, 6, num_timesteps)
-        betas = torch.sigmoid(betas) * (end - start) + start
-    elif schedule == "cosine" or schedule == "cosine_reverse":
-        max_beta = 0.999
-        cosine_s = 0.008
-        betas = torch.tensor(
-            [min(1 - (math.cos(((i + 1) / num_timesteps + cosine_s) / (1 + cosine_s) * math.pi / 2) ** 2) / (
-                math.cos((i / num_timesteps + cosine_s) / (1 + cosine_s) * math.pi / 2) ** 2), max_beta)
-             for i in range(num_timesteps)])
-    elif schedule == "cosine_anneal":
-        betas = torch.tensor(
-            [start + 0.5 * (end - start) * (1 - math.cos(t / (num_timesteps - 1) * math.pi))
-             for t in range(num_timesteps)])
-    else:
-        raise ValueError(f"unknown beta schedule '{schedule}'")
-    return betas
+        return torch.linspace(start, end, T)
+    if schedule == "const":
+        return end * torch.ones(T)
+    if schedule == "quad":
+        return torch.linspace(start ** 0.5, end ** 0.5, T) ** 2
+    if schedule == "jsd":
+        return 1.0 / torch.linspace(T, 1, T)
+    if schedule == "sigmoid":
+        return torch.sigmoid(torch.linspace(-6, 6, T)) * (end - start) + start
+    if schedule in ("cosine", "cosine_reverse"):
+        # beta_i = min(1 - abar((i+1)/T) / abar(i/T), 0.999), abar(u) = cos^2(((u + 0.008) / 1.008) * pi / 2)
+        return torch.tensor([min(1 - _cosine_alpha_bar((i + 1) / T) / _cosine_alpha_bar(i / T), 0.999) for i in range(T)])
+    if schedule == "cosine_anneal":
+        return torch.tensor([start + 0.5 * (end - start) * (1 - math.cos(t / (T - 1) * math.pi)) for t in range(T)])
+    raise ValueError(f"unknown beta schedule '{schedule}'")
 
 
 def extract(input, t, x):

@@ -34,31 +34,27 @@ LN_EPS = 1e-6          # timm 0.4.12 vit_base_patch16_224: partial(nn.LayerNorm,
 # ----------------------------------------------------------------------------
 def make_beta_schedule(schedule: str = "linear", num_timesteps: int = 1000,
                        start: float = 1e-5, end: float = 1e-2) -> Tensor:
-    """diffusion/diffusion_utils.py:5-28 (all branches)."""
-    if schedule == "linear":
-        betas = torch.linspace(start, end, num_timesteps)
-    elif schedule == "const":
-        betas = end * torch.ones(num_timesteps)
-    elif schedule == "quad":
-        betas = torch.linspace(start ** 0.5, end ** 0.5, num_timesteps) ** 2
-    elif schedule == "jsd":
-        betas = 1.0 / torch.linspace(num_timesteps, 1, num_timesteps)
-    elif schedule == "sigmoid":
-        betas = torch.linspace(-6, 6, num_timesteps)
-        betas = torch.sigmoid(betas) * (end - start) + start
-    elif schedule in ("cosine", "cosine_reverse"):
-        max_beta, cosine_s = 0.999, 0.008
-        betas = torch.tensor([
-            min(1 - (math.cos(((i + 1) / num_timesteps + cosine_s) / (1 + cosine_s) * math.pi / 2) ** 2)
-                / (math.cos((i / num_timesteps + cosine_s) / (1 + cosine_s) * math.pi / 2) ** 2), max_beta)
-            for i in range(num_timesteps)])
-    elif schedule == "cosine_anneal":
-        betas = torch.tensor([
-            start + 0.5 * (end - start) * (1 - math.cos(t / (num_timesteps - 1) * math.pi))
-            for t in range(num_timesteps)])
-    else:
+    """diffusion/diffusion_utils.py:5-28, every branch, same torch ops (pinned bit-exact by schedule.npz)."""
+    T = num_timesteps
+    lin = torch.linspace
+
+    def abar(u, s=0.008):                       # cosine schedule's alpha-bar (:18-23)
+        return math.cos((u + s) / (1 + s) * math.pi / 2) ** 2
+
+    table = {
+        "linear": lambda: lin(start, end, T),
+        "const": lambda: end * torch.ones(T),
+        "quad": lambda: lin(start ** 0.5, end ** 0.5, T) ** 2,
+        "jsd": lambda: 1.0 / lin(T, 1, T),
+        "sigmoid": lambda: torch.sigmoid(lin(-6, 6, T)) * (end - start) + start,
+        "cosine": lambda: torch.tensor([min(1 - abar((i + 1) / T) / abar(i / T), 0.999) for i in range(T)]),
+        "cosine_anneal": lambda: torch.tensor([start + 0.5 * (end - start) * (1 - math.cos(t / (T - 1) * math.pi))
+                                               for t in range(T)]),
+    }
+    table["cosine_reverse"] = table["cosine"]
+    if schedule not in table:
         raise ValueError(schedule)
-    return betas
+    return table[schedule]()
 
 
 def schedule_tables(schedule: str, num_timesteps: int, start: float, end: float):
