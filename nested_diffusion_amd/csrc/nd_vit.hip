@@ -3,6 +3,7 @@
 // f32-input MFMA (exact f32 products).
 #include "nd_common.hpp"
 #include "../../include/nested_diffusion.h"
+#include <cstdlib>
 
 int nd_set_err(int code, const char* fmt, ...);
 #define HIP_CHECK(expr)                                                                              \
@@ -236,13 +237,15 @@ extern "C" int nd_layernorm(const float* x, const float* gamma, const float* bet
 //                   so no transpose or LDS is needed.  D_e[i=4g'+r'][q] holds d = 4*i + e.
 // ---------------------------------------------------------------------------------------------
 #define AT_MAXF 16  // up to 256 keys
-template <int NF>
-__global__ __launch_bounds__(256) void k_attention_d64(const float* __restrict__ qkv, float* __restrict__ out, int B, int N,
+// QF = 16-row query fragments per wave: every K / V fragment load feeds QF times the MFMAs (the kernel is bound by the
+// L2 -> L1 stream of K/V, 256 B per MFMA at QF = 1).
+template <int NF, int QF, int MINW>
+__global__ __launch_bounds__(256, MINW) void k_attention_d64(const float* __restrict__ qkv, float* __restrict__ out, int B, int N,
                                                        int heads) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int qf = blockIdx.x * 4 + wave;                 // 16-row query fragment
+    const int qf0 = (blockIdx.x * 4 + wave) * QF;          // first 16-row query fragment of this wave
     const int bh = blockIdx.y, b = bh / heads, hd = bh % heads;
-    if (qf * 16 >= N) return;
+    if (qf0 * 16 >= N) return;
     const int Cm = heads * 64;
     const size_t rs = (size_t)3 * Cm;                      // token stride in qkv
     const float* base = qkv + (size_t)b * N * rs + (size_t)hd * 64;
@@ -250,26 +253,141 @@ __global__ __launch_bounds__(256) void k_attention_d64(const float* __restrict__
     const float* kb = base + Cm;
     const float* vb = base + 2 * Cm;
     const int g = lane >> 4, li = lane & 15;
-    const int qrow = min(qf * 16 + li, N - 1);
-    float4 qv[4];
+    float4 qv[QF][4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) qv[c] = *reinterpret_cast<const float4*>(qb + (size_t)qrow * rs + 16 * c + 4 * g);
-
-    f32x4 s[NF];
+    for (int u = 0; u < QF; ++u) {
+        const int qrow = min((qf0 + u) * 16 + li, N - 1);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) qv[u][c] = *reinterpret_cast<const float4*>(qb + (size_t)qrow * rs + 16 * c + 4 * g);
+    }
+    f32x4 s[QF][NF];
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
-        s[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < QF; ++u) s[u][f] = f32x4{0.f, 0.f, 0.f, 0.f};
         const int krow = min(16 * f + li, N - 1);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const float4 kv = *reinterpret_cast<const float4*>(kb + (size_t)krow * rs + 16 * c + 4 * g);
+#pragma unroll
+            for (int u = 0; u < QF; ++u) {
+                s[u][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(kv.x, qv[u][c].x, s[u][f], 0, 0, 0);
+                s[u][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(kv.y, qv[u][c].y, s[u][f], 0, 0, 0);
+                s[u][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(kv.z, qv[u][c].z, s[u][f], 0, 0, 0);
+                s[u][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(kv.w, qv[u][c].w, s[u][f], 0, 0, 0);
+            }
+        }
+    }
+    // scale, mask invalid keys, softmax over keys (per query column q = lane & 15)
+    const float scale = 0.125f;  // 64^-0.5
+    float inv[QF];
+#pragma unroll
+    for (int u = 0; u < QF; ++u) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int f = 0; f < NF; ++f)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = 16 * f + 4 * g + r;
+                const float v = key < N ? s[u][f][r] * scale : -INFINITY;
+                s[u][f][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int f = 0; f < NF; ++f)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = expf(s[u][f][r] - mx);
+                s[u][f][r] = p;
+                sum += p;
+            }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        inv[u] = 1.0f / sum;
+    }
+    f32x4 o[QF][4];
+#pragma unroll
+    for (int u = 0; u < QF; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[u][e] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int key = min(16 * f + 4 * g + r, N - 1);
+            const float4 vv = *reinterpret_cast<const float4*>(vb + (size_t)key * rs + 4 * li);
+#pragma unroll
+            for (int u = 0; u < QF; ++u) {
+                const float p = s[u][f][r] * inv[u];     // normalised first, as torch (softmax then @ v)
+                o[u][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv.x, p, o[u][0], 0, 0, 0);
+                o[u][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv.y, p, o[u][1], 0, 0, 0);
+                o[u][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv.z, p, o[u][2], 0, 0, 0);
+                o[u][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv.w, p, o[u][3], 0, 0, 0);
+            }
+        }
+    // o[u][e][r'] = O[q = l&15][d = 4*(4g + r') + e]  ->  float4 over e at d0 = 16g + 4r'
+#pragma unroll
+    for (int u = 0; u < QF; ++u) {
+        const int qo = (qf0 + u) * 16 + li;
+        if (qo < N) {
+            float* op = out + ((size_t)b * N + qo) * Cm + (size_t)hd * 64 + 16 * g;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) *reinterpret_cast<float4*>(op + 4 * r) = make_float4(o[u][0][r], o[u][1][r], o[u][2][r], o[u][3][r]);
+        }
+    }
+}
+
+// LDS form: one workgroup per (batch, head); its ceil(N/16) waves (one 16-row query fragment each) share the head's K
+// and V, staged once into LDS with coalesced float4 loads.  Rows are padded to 68 floats so the MFMA-operand reads
+// (ds_read_b128: K by (key = l&15, d-quad), V by (key = 4g+r, d = 4*(l&15))) are at most 2-way bank conflicted; rows
+// N .. 16*NF-1 are zero-filled, so no clamping in the inner loops.  Same arithmetic and operand maps as above.
+#define AT_LD 68
+template <int NF>
+__global__ __launch_bounds__(NF * 64) void k_attention_lds(const float* __restrict__ qkv, float* __restrict__ out, int B, int N,
+                                                            int heads) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sK = smem;                       // [16*NF][AT_LD]
+    float* sV = smem + 16 * NF * AT_LD;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bh = blockIdx.x, b = bh / heads, hd = bh % heads;
+    const int Cm = heads * 64;
+    const size_t rs = (size_t)3 * Cm;
+    const float* base = qkv + (size_t)b * N * rs + (size_t)hd * 64;
+    const float* qb = base;
+    const float* kb = base + Cm;
+    const float* vb = base + 2 * Cm;
+    for (int e = tid; e < 16 * NF * 16; e += NF * 64) {          // 16 float4 per 64-float row
+        const int row = e >> 4, c4 = (e & 15) * 4;
+        float4 k4 = make_float4(0.f, 0.f, 0.f, 0.f), v4 = k4;
+        if (row < N) {
+            k4 = *reinterpret_cast<const float4*>(kb + (size_t)row * rs + c4);
+            v4 = *reinterpret_cast<const float4*>(vb + (size_t)row * rs + c4);
+        }
+        *reinterpret_cast<float4*>(sK + row * AT_LD + c4) = k4;
+        *reinterpret_cast<float4*>(sV + row * AT_LD + c4) = v4;
+    }
+    const int g = lane >> 4, li = lane & 15;
+    const int qrow = min(wave * 16 + li, N - 1);
+    float4 qv[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) qv[c] = *reinterpret_cast<const float4*>(qb + (size_t)qrow * rs + 16 * c + 4 * g);
+    __syncthreads();
+    f32x4 s[NF];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+        s[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float4 kv = *reinterpret_cast<const float4*>(sK + (16 * f + li) * AT_LD + 16 * c + 4 * g);
             s[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(kv.x, qv[c].x, s[f], 0, 0, 0);
             s[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(kv.y, qv[c].y, s[f], 0, 0, 0);
             s[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(kv.z, qv[c].z, s[f], 0, 0, 0);
             s[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(kv.w, qv[c].w, s[f], 0, 0, 0);
         }
     }
-    // scale, mask invalid keys, softmax over keys (per query column q = lane & 15)
     const float scale = 0.125f;  // 64^-0.5
     float mx = -INFINITY;
 #pragma unroll
@@ -295,7 +413,6 @@ __global__ __launch_bounds__(256) void k_attention_d64(const float* __restrict__
     sum += __shfl_xor(sum, 16, 64);
     sum += __shfl_xor(sum, 32, 64);
     const float inv = 1.0f / sum;
-
     f32x4 o[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -303,21 +420,32 @@ __global__ __launch_bounds__(256) void k_attention_d64(const float* __restrict__
     for (int f = 0; f < NF; ++f)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int key = min(16 * f + 4 * g + r, N - 1);
-            const float4 vv = *reinterpret_cast<const float4*>(vb + (size_t)key * rs + 4 * li);
-            const float p = s[f][r] * inv;     // normalised first, as torch (softmax then @ v)
+            const float4 vv = *reinterpret_cast<const float4*>(sV + (16 * f + 4 * g + r) * AT_LD + 4 * li);
+            const float p = s[f][r] * inv;
             o[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv.x, p, o[0], 0, 0, 0);
             o[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv.y, p, o[1], 0, 0, 0);
             o[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv.z, p, o[2], 0, 0, 0);
             o[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv.w, p, o[3], 0, 0, 0);
         }
-    // o[e][r'] = O[q = l&15][d = 4*(4g + r') + e]  ->  float4 over e at d0 = 16g + 4r'
-    const int qo = qf * 16 + li;
+    const int qo = wave * 16 + li;
     if (qo < N) {
         float* op = out + ((size_t)b * N + qo) * Cm + (size_t)hd * 64 + 16 * g;
 #pragma unroll
         for (int r = 0; r < 4; ++r) *reinterpret_cast<float4*>(op + 4 * r) = make_float4(o[0][r], o[1][r], o[2][r], o[3][r]);
     }
+}
+
+template <int NF>
+static hipError_t launch_attention_lds(const float* qkv, float* out, int B, int N, int heads, hipStream_t st) {
+    const size_t lds = (size_t)2 * 16 * NF * AT_LD * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_attention_lds<NF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_attention_lds<NF>), dim3(B * heads), dim3(NF * 64), lds, st, qkv, out, B, N, heads);
+    return hipGetLastError();
 }
 
 extern "C" int nd_attention(const float* qkv, float* out, int B, int N, int heads, int d, void* stream) {
@@ -326,8 +454,10 @@ extern "C" int nd_attention(const float* qkv, float* out, int B, int N, int head
     if (B < 1 || heads < 1 || N < 1 || N > 16 * AT_MAXF) return nd_set_err(ND_ERR_ARG, "need 1 <= N <= %d", 16 * AT_MAXF);
     hipStream_t st = (hipStream_t)stream;
     const int nf = (N + 15) / 16;
+    static const int form = getenv("ND_ATT_FORM") ? atoi(getenv("ND_ATT_FORM")) : 1;   // 1 = K/V in LDS, 0 = K/V from L2 per wave
     const dim3 grid((nf + 3) / 4, B * heads), block(256);
-#define AT_CASE(NFV) case NFV: hipLaunchKernelGGL((k_attention_d64<NFV>), grid, block, 0, st, qkv, out, B, N, heads); break;
+#define AT_CASE(NFV) case NFV: if (form == 1) HIP_CHECK((launch_attention_lds<NFV>(qkv, out, B, N, heads, st))); \
+                               else hipLaunchKernelGGL((k_attention_d64<NFV, 1, 2>), grid, block, 0, st, qkv, out, B, N, heads); break;
     switch (nf) {
         AT_CASE(1) AT_CASE(2) AT_CASE(3) AT_CASE(4) AT_CASE(5) AT_CASE(6) AT_CASE(7) AT_CASE(8)
         AT_CASE(9) AT_CASE(10) AT_CASE(11) AT_CASE(12) AT_CASE(13) AT_CASE(14) AT_CASE(15) AT_CASE(16)
