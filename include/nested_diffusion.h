@@ -155,9 +155,13 @@ int nd_linear(const float *x_dev, const float *w_packed_dev, const float *scale_
 
 /* Large-M GEMM for the ViT blocks: out[M,N] = act(x[M,K] . W[N,K]^T + bias[n]) (+ residual[M,N]).
  * timm 0.4.12 Attention.qkv / proj, Mlp.fc1 (GELU) / fc2, PatchEmbed.proj as GEMM
- * (call sites classification_train_separately.py:337-340). */
+ * (call sites classification_train_separately.py:337-340).
+ * workspace_dev (>= nd_gemm_workspace_bytes(M, K, N), 16-byte aligned; may be NULL/0): lets the last, partly filled round
+ * of output tiles be cut along K across the idle CUs; without it every tile is computed whole (same sums, other order). */
+size_t nd_gemm_workspace_bytes(int M, int K, int N);
 int nd_gemm_bias_act(const float *x_dev, const float *w_dev, const float *bias_dev, const float *residual_dev,
-                     float *out_dev, int M, int K, int N, int act, void *stream);
+                     float *out_dev, int M, int K, int N, int act, void *workspace_dev, size_t workspace_bytes,
+                     void *stream);
 
 /* nn.LayerNorm(eps) over the last dim: x [rows, dim] -> out.  timm Block.norm1/norm2 (eps 1e-6). */
 int nd_layernorm(const float *x_dev, const float *gamma_dev, const float *beta_dev, float *out_dev,

@@ -29,7 +29,8 @@ int nd_set_err(int code, const char* fmt, ...);
 template <int BM, int BN>
 __global__ __launch_bounds__(256) void k_gemm_nt(const float* __restrict__ x, const float* __restrict__ w,
                                                  const float* __restrict__ bias, const float* __restrict__ res,
-                                                 float* __restrict__ out, int M, int K, int N, int act) {
+                                                 float* __restrict__ out, int M, int K, int N, int act, int n_full,
+                                                 int split, float* __restrict__ part) {
     constexpr int WM = BM / 2, WN = BN / 2;      // per-wave tile
     constexpr int FM = WM / 16, FN = WN / 16;    // 16x16 fragments per wave
     constexpr int LA = BM * GB_K / 4 / 256;      // float4 loads per thread for the x tile
@@ -40,12 +41,17 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const float* __restrict__ x, co
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     // XCD-aware tile order: consecutive tiles along N (sharing the x panel) land on one XCD
-    const int tiles_n = (N + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
-    const int nwg = tiles_m * tiles_n;
-    int bid = blockIdx.x;
-    {
-        const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, loc = bid / 8;
+    const int tiles_n = (N + BN - 1) / BN;
+    // Workgroups [0, n_full) take one whole tile each; the remaining tiles are cut into `split` k-slabs, one workgroup per
+    // slab, whose raw sums go to `part` and are finished by k_gemm_fixup (the tail of the launch is then `split` times finer).
+    int bid = blockIdx.x, slab = -1;
+    if (bid < n_full) {
+        const int q = n_full / 8, r = n_full % 8, xcd = bid % 8, loc = bid / 8;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    } else {
+        const int j = bid - n_full;
+        bid = n_full + j / split;
+        slab = j % split;
     }
     const int tm = bid / tiles_n, tn = bid % tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
@@ -82,12 +88,14 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const float* __restrict__ x, co
         }                                                                                                 \
     }
 
-    const int nk = K / GB_K;
-    GB_GLOAD(0)
-    GB_SWRITE(0)
+    const int nkt = K / GB_K;
+    const int ks0 = slab < 0 ? 0 : (int)((long)slab * nkt / split);
+    const int nk = slab < 0 ? nkt : (int)((long)(slab + 1) * nkt / split);
+    GB_GLOAD(ks0 * GB_K)
+    GB_SWRITE(ks0 & 1)
     __syncthreads();
     const int lr = lane & 15, lk = 4 * (lane >> 4);
-    for (int ks = 0; ks < nk; ++ks) {
+    for (int ks = ks0; ks < nk; ++ks) {
         const int buf = ks & 1;
         // unconditional (clamped) prefetch + write-back: conditionally assigned staging arrays are kept in scratch
         // memory by hipcc; the last step re-stages a valid tile that nobody reads
@@ -117,6 +125,16 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const float* __restrict__ x, co
 #undef GB_GLOAD
 #undef GB_SWRITE
     // D[n = 4*(l>>4)+r][m = l&15]: a lane owns 4 consecutive n of one row m
+    if (slab >= 0) {
+        float* pt = part + ((size_t)(bid - n_full) * split + slab) * (BM * BN);
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+                *reinterpret_cast<float4*>(pt + (wr * WM + 16 * i + (lane & 15)) * BN + wc * WN + 16 * j + 4 * (lane >> 4)) =
+                    make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
         const int m = m0 + wr * WM + 16 * i + (lane & 15);
@@ -145,20 +163,93 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const float* __restrict__ x, co
 }
 
 
+// Finishes the k-split tiles: out = act(sum_slabs part + bias) + res, slabs added in order (reproducible).
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void k_gemm_fixup(const float* __restrict__ part, const float* __restrict__ bias,
+                                                    const float* __restrict__ res, float* __restrict__ out, int M, int N, int act,
+                                                    int n_full, int split) {
+    const int tiles_n = (N + BN - 1) / BN;
+    const int tile = n_full + blockIdx.y;
+    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+    const int e = blockIdx.x * 256 + threadIdx.x;           // float4 index inside the tile
+    const int ml = e / (BN / 4), nl = (e % (BN / 4)) * 4;
+    const int m = m0 + ml, n = n0 + nl;
+    if (m >= M || n >= N) return;
+    const float* pt = part + (size_t)blockIdx.y * split * (BM * BN) + (size_t)ml * BN + nl;
+    float4 s4 = *reinterpret_cast<const float4*>(pt);
+    for (int k = 1; k < split; ++k) {
+        const float4 v = *reinterpret_cast<const float4*>(pt + (size_t)k * (BM * BN));
+        s4.x += v.x; s4.y += v.y; s4.z += v.z; s4.w += v.w;
+    }
+    float v[4] = {s4.x, s4.y, s4.z, s4.w};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int nn = min(n + r, N - 1);
+        float t = v[r] + (bias ? bias[nn] : 0.f);
+        t = nd_act(t, act);
+        if (res && n + r < N) t += res[(size_t)m * N + n + r];
+        v[r] = t;
+    }
+    float* p = out + (size_t)m * N + n;
+    if (n + 3 < N && (N & 3) == 0) *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (n + r < N) p[r] = v[r];
+    }
+}
+
+// Launch plan.  Measured (tools/bench_gemm2.py): the run time of a launch is ceil(tiles / 256) x (time of one tile), i.e. it
+// is quantised on whole tiles per CU, and the 128x64 tile is as fast as 128x128 per flop.  So: 128x64 tiles; the
+// tiles % 256 remainder is cut into `split` k-slabs where that shortens the last round (needs the workspace).
+#define GT_BM 128
+#define GT_BN 64
+#define GT_CUS 256
+struct GemmPlan { int tiles, n_full, rem, split; size_t ws_bytes; };
+static GemmPlan nd_gemm_plan(int M, int K, int N) {
+    GemmPlan p{};
+    p.tiles = ((M + GT_BM - 1) / GT_BM) * ((N + GT_BN - 1) / GT_BN);
+    p.n_full = (p.tiles / GT_CUS) * GT_CUS;
+    p.rem = p.tiles - p.n_full;
+    p.split = 1;
+    const int nk = K / GB_K;
+    if (p.rem > 0 && (size_t)M * N * K >= ((size_t)1 << 28)) {
+        // tail length in tile-times: ceil(rem * s / 256) / s ; take the smallest s that gets within 10 % of the best
+        double best = 1e9;
+        const int cand[] = {1, 2, 3, 4, 5, 6, 8};
+        for (int s : cand) if (nk / s >= 8) best = fmin(best, (double)((p.rem * s + GT_CUS - 1) / GT_CUS) / s);
+        for (int s : cand)
+            if (nk / s >= 8 && (double)((p.rem * s + GT_CUS - 1) / GT_CUS) / s <= best * 1.1 + 1e-9) { p.split = s; break; }
+    }
+    p.ws_bytes = p.split > 1 ? (size_t)p.rem * p.split * GT_BM * GT_BN * sizeof(float) : 0;
+    return p;
+}
+
+extern "C" size_t nd_gemm_workspace_bytes(int M, int K, int N) {
+    if (M < 1 || N < 1 || K < 16 || (K % 16)) return 0;
+    return nd_gemm_plan(M, K, N).ws_bytes;
+}
+
 extern "C" int nd_gemm_bias_act(const float* x, const float* w, const float* bias, const float* res, float* out, int M, int K,
-                                int N, int act, void* stream) {
+                                int N, int act, void* workspace, size_t workspace_bytes, void* stream) {
     if (!x || !w || !out) return nd_set_err(ND_ERR_ARG, "NULL tensor");
     if (M < 1 || N < 1 || K < 16 || (K % 16)) return nd_set_err(ND_ERR_ARG, "need M,N >= 1 and K a positive multiple of 16 (K=%d)", K);
     if (act < 0 || act > 3) return nd_set_err(ND_ERR_ARG, "unknown activation %d", act);
     hipStream_t st = (hipStream_t)stream;
-    const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
-    if (t128 >= 512) {
-        hipLaunchKernelGGL((k_gemm_nt<128, 128>), dim3((unsigned)t128), dim3(256), 0, st, x, w, bias, res, out, M, K, N, act);
-    } else {
-        const long t = (long)((M + 127) / 128) * ((N + 63) / 64);
-        hipLaunchKernelGGL((k_gemm_nt<128, 64>), dim3((unsigned)t), dim3(256), 0, st, x, w, bias, res, out, M, K, N, act);
+    GemmPlan p = nd_gemm_plan(M, K, N);
+    if (p.split > 1 && (!workspace || workspace_bytes < p.ws_bytes || ((uintptr_t)workspace & 15))) {
+        // no (or too small / misaligned) workspace: every tile whole -- same results up to summation order, longer tail
+        p.n_full = p.tiles; p.rem = 0; p.split = 1;
     }
+    if (p.split == 1) { p.n_full = p.tiles; p.rem = 0; }
+    float* part = (float*)workspace;
+    hipLaunchKernelGGL((k_gemm_nt<GT_BM, GT_BN>), dim3((unsigned)(p.n_full + p.rem * p.split)), dim3(256), 0, st, x, w, bias, res, out,
+                       M, K, N, act, p.n_full, p.split, part);
     HIP_CHECK(hipGetLastError());
+    if (p.rem > 0) {
+        hipLaunchKernelGGL((k_gemm_fixup<GT_BM, GT_BN>), dim3(GT_BM * GT_BN / 4 / 256, p.rem), dim3(256), 0, st, part, bias, res, out, M, N,
+                           act, p.n_full, p.split);
+        HIP_CHECK(hipGetLastError());
+    }
     return ND_OK;
 }
 

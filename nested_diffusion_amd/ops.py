@@ -90,8 +90,10 @@ def gemm_bias_act(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Te
     if residual is not None and tuple(residual.shape) != (M, N):
         raise ValueError("residual must be [M, N]")
     out = torch.empty(M, N, dtype=torch.float32, device=x.device)
-    check(lib.nd_gemm_bias_act(ptr(x), ptr(weight), ptr(bias), ptr(residual), ptr(out), M, K, N, ACT[act], _stream(x)),
-          "nd_gemm_bias_act")
+    nbytes = lib.nd_gemm_workspace_bytes(M, K, N)
+    ws = _workspace(nbytes, x.device) if nbytes else None
+    check(lib.nd_gemm_bias_act(ptr(x), ptr(weight), ptr(bias), ptr(residual), ptr(out), M, K, N, ACT[act], ptr(ws),
+                               ws.numel() if ws is not None else 0, _stream(x)), "nd_gemm_bias_act")
     return out
 
 

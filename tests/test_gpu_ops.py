@@ -49,6 +49,8 @@ def test_linear_splitk(M, K, N):
 
 
 @pytest.mark.parametrize("M,K,N,act,res", [(6272, 768, 768, None, True), (392, 768, 2304, None, False),
+                                           (6250, 768, 3070, "gelu", True), (6272, 3072, 768, None, True),   # k-split tail tiles
+
                                            (200, 64, 256, "gelu", False), (130, 48, 70, None, True), (1, 16, 1, "relu", False)])
 def test_gemm_bias_act(M, K, N, act, res):
     from nested_diffusion_amd import ops
@@ -63,6 +65,25 @@ def test_gemm_bias_act(M, K, N, act, res):
     if res:
         ref = ref + r
     _close(out, ref, 2e-5)
+
+
+def test_gemm_without_workspace_matches_split_path():
+    """nd_gemm_bias_act with a NULL workspace computes every tile whole: same values up to summation order."""
+    from nested_diffusion_amd import _lib, ops
+    lib = _lib.load()
+    M, K, N = 6272, 768, 768
+    assert lib.nd_gemm_workspace_bytes(M, K, N) > 0                     # this shape takes the k-split tail
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(M, K, generator=g).cuda()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    a = ops.gemm_bias_act(x, w, b)
+    out = torch.empty(M, N, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.nd_gemm_bias_act(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), None, _lib.ptr(out), M, K, N, 0, None, 0, st), "gemm")
+    torch.cuda.synchronize()
+    assert (a - out).abs().max().item() < 2e-5
+    assert torch.equal(a, ops.gemm_bias_act(x, w, b))                    # reproducible run to run
 
 
 @pytest.mark.parametrize("rows,dim", [(5, 768), (197 * 3, 768), (7, 64), (3, 1024), (2, 2048)])
