@@ -2,7 +2,7 @@
 diffusion/classification_train_separately.py -- __init__ schedule block (:215-226), conditioner
 loading (:249-275), compute_guiding_prediction (:330-348), convert_to_prob (:392-398),
 compute_ensemble_confidence (:425-447), majority_voting_for_mc_samples (:51-68) and the hot loop
-of test_atk (:749-794).  Training, calibration and the reporting metrics are out of scope.
+of test_atk (:749-794), plus the report metrics and test_calibrate.  Training and attacks are out of scope.
 
 Host code is PyTorch plumbing; every tensor operation of the hot path runs in libnd_hip.so.
 """
