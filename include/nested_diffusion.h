@@ -52,7 +52,13 @@ typedef struct {
     int32_t n_members;   /* K  */
     int32_t max_batch;   /* largest B (images) per call */
     int32_t max_rows;    /* largest M = B * mc_trials per call */
+    int32_t operand_dtype; /* ND_DTYPE_F32 (0): the reference's arithmetic.  ND_DTYPE_F16 (1): weights of the five large Linear
+                            * layers and their input activations are held in fp16 (products exact, fp32 accumulation, fp32
+                            * epilogues, tables and state) -- BASELINE config 5; the reference has no such mode.  Needs
+                            * data_dim, hidden_dim, feature_dim % 32 == 0. */
 } nd_config;
+#define ND_DTYPE_F32 0
+#define ND_DTYPE_F16 1
 
 /* Device pointers to ONE member's raw parameters, exactly the tensors of
  * ConditionalModel.state_dict() (key in the comment; shapes for config dims). */
@@ -140,17 +146,19 @@ int nd_member_buffer(nd_handle h, int member, int which, float *dst_dev, int row
 /* ---- standalone operators (mapping network + unit tests) ---------------------------------- */
 /* "frag16" packing of a K-contiguous matrix [R, K] (K % 16 == 0) into the MFMA fragment order the
  * weight-streaming kernels read with fully coalesced 1 KiB wave loads (layout: DESIGN.md).  Rows are
- * padded to a multiple of 16 with zeros.  Weights are packed once (mapping-MLP load time). */
-size_t nd_packed_bytes(int R, int K);
-int nd_pack_rows(const float *src_dev, float *dst_packed_dev, int R, int K, void *stream);
+ * padded to a multiple of 16 with zeros.  Weights are packed once (mapping-MLP load time).
+ * dtype ND_DTYPE_F16: the "frag32h" image (fp16, round to nearest even, K % 32 == 0) for the fp16-operand mode. */
+size_t nd_packed_bytes(int R, int K, int dtype);
+int nd_pack_rows(const float *src_dev, void *dst_packed_dev, int R, int K, int dtype, void *stream);
 
 /* out[M,N] = act(scale[n] * (x[M,K] . W[N,K]^T) + shift[n]); scale/shift may be NULL (1 / 0).
- * nn.Linear + bias (+ReLU) of mapping/models/mlp.py:25-28 with shift = bias.  x and out are row-major,
- * w_packed_dev is the nd_pack_rows image of the [N, K] nn.Linear weight.  Skinny-M weight streaming;
- * split-K across workgroups when K is large.  workspace_dev: >= nd_linear_workspace_bytes(M, K, N). */
-size_t nd_linear_workspace_bytes(int M, int K, int N);
-int nd_linear(const float *x_dev, const float *w_packed_dev, const float *scale_dev, const float *shift_dev,
-              float *out_dev, int M, int K, int N, int act, void *workspace_dev, size_t workspace_bytes,
+ * nn.Linear + bias (+ReLU) of mapping/models/mlp.py:25-28 with shift = bias.  x and out are row-major fp32,
+ * w_packed_dev is the nd_pack_rows image (same dtype) of the [N, K] nn.Linear weight.  Skinny-M weight streaming;
+ * split-K across workgroups when K is large.  workspace_dev: >= nd_linear_workspace_bytes(M, K, N, dtype).
+ * dtype ND_DTYPE_F16: x is rounded to fp16 on the way in, products exact, fp32 accumulation and epilogue. */
+size_t nd_linear_workspace_bytes(int M, int K, int N, int dtype);
+int nd_linear(const float *x_dev, const void *w_packed_dev, const float *scale_dev, const float *shift_dev,
+              float *out_dev, int M, int K, int N, int act, int dtype, void *workspace_dev, size_t workspace_bytes,
               void *stream);
 
 /* Large-M GEMM for the ViT blocks: out[M,N] = act(x[M,K] . W[N,K]^T + bias[n]) (+ residual[M,N]).

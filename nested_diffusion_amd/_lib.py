@@ -14,6 +14,17 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libnd_hip.so")
 
 ND_ACT_NONE, ND_ACT_SOFTPLUS, ND_ACT_RELU, ND_ACT_GELU = 0, 1, 2, 3
+ND_DTYPE_F32, ND_DTYPE_F16 = 0, 1
+
+
+def dtype_code(dtype) -> int:
+    """'f32' | 'f16' (also 'fp32'/'fp16', torch.float32/float16) -> ND_DTYPE_*."""
+    name = str(dtype).replace("torch.", "").lower()
+    if name in ("f32", "fp32", "float32", "0"):
+        return ND_DTYPE_F32
+    if name in ("f16", "fp16", "float16", "half", "1"):
+        return ND_DTYPE_F16
+    raise ValueError(f"operand dtype must be 'f32' or 'f16', got {dtype!r}")
 
 # field order MUST match nd_member_weights in include/nested_diffusion.h
 MEMBER_WEIGHT_FIELDS = [
@@ -41,7 +52,7 @@ MEMBER_WEIGHT_FIELDS = [
 
 class NdConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("y_dim", "data_dim", "hidden_dim", "feature_dim", "n_steps",
-                                          "n_members", "max_batch", "max_rows")]
+                                          "n_members", "max_batch", "max_rows", "operand_dtype")]
 
 
 class NdMemberWeights(C.Structure):
@@ -66,10 +77,10 @@ SIGNATURES = {
     "nd_set_profiling": (_i, [_vp, _i]),
     "nd_profile_read": (_i, [_vp, C.POINTER(C.c_float), C.POINTER(_i)]),
     "nd_member_buffer": (_i, [_vp, _i, _i, _vp, _i, _vp]),
-    "nd_packed_bytes": (_sz, [_i, _i]),
-    "nd_pack_rows": (_i, [_vp, _vp, _i, _i, _vp]),
-    "nd_linear_workspace_bytes": (_sz, [_i, _i, _i]),
-    "nd_linear": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "nd_packed_bytes": (_sz, [_i, _i, _i]),
+    "nd_pack_rows": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "nd_linear_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "nd_linear": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "nd_gemm_workspace_bytes": (_sz, [_i, _i, _i]),
     "nd_gemm_bias_act": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
     "nd_layernorm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp]),

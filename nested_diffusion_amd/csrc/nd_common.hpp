@@ -18,6 +18,8 @@
 #include <stdint.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 #define ND_ACT_NONE 0
 #define ND_ACT_SOFTPLUS 1
@@ -43,6 +45,55 @@ __host__ __device__ __forceinline__ size_t nd_pk(int r, int k, int nch) {
     return ((size_t)(r >> 4) * nch + (k >> 4)) * 256 + (size_t)(((r & 15) + 16 * ((k & 15) >> 2)) * 4 + (k & 3));
 }
 static inline size_t nd_packed_floats(int R, int K) { return (size_t)((R + 15) / 16) * 16 * (size_t)K; }
+
+// HALF-PRECISION OPERANDS ("frag32h", the fp16 mode).  Same idea with 16-row x 32-column blocks of fp16, again 1 KiB:
+// block (r/16, k/32) at BYTE offset ((r/16)*(K/32) + k/32)*1024, element (r, k) inside it at half index
+// ((r%16) + 16*((k%32)/8))*8 + k%8 -- lane l of a wave holds the 8 halfs k = 8*(l>>4)..+7 of row l&15, the operand
+// shape of v_mfma_f32_16x16x32_f16.  A block is 256 float-sized words like a frag16 block, so the streaming kernels
+// address both forms identically with nch = K/32 instead of K/16.  Products are exact, accumulation is fp32.
+__host__ __device__ __forceinline__ size_t nd_pkh(int r, int k, int nch32) {   // half index
+    return ((size_t)(r >> 4) * nch32 + (k >> 5)) * 512 + (size_t)(((r & 15) + 16 * ((k & 31) >> 3)) * 8 + (k & 7));
+}
+static inline size_t nd_packed_bytes_dt(int R, int K, int half) {
+    return (size_t)((R + 15) / 16) * 16 * (size_t)K * (half ? 2 : 4);
+}
+
+// row-major fp32 [R][K] -> frag32h (round to nearest even); rows R .. 16*ceil(R/16) zero-filled.  16 B per thread.
+static __global__ __launch_bounds__(256) void k_pack_rows_h(const float* __restrict__ src, _Float16* __restrict__ dst, int R, int K) {
+    const int nch = K >> 5;
+    const size_t total = (size_t)((R + 15) / 16) * nch * 64;   // 16-byte pieces
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int lane = (int)(i & 63);
+        const size_t blk = i >> 6;
+        const int rt = (int)(blk / nch), c = (int)(blk % nch);
+        const int r = rt * 16 + (lane & 15);
+        f16x8 h = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (r < R) {
+            const float* p = src + (size_t)r * K + c * 32 + 8 * (lane >> 4);
+            const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+            h = f16x8{(_Float16)a.x, (_Float16)a.y, (_Float16)a.z, (_Float16)a.w, (_Float16)b.x, (_Float16)b.y, (_Float16)b.z, (_Float16)b.w};
+        }
+        reinterpret_cast<f16x8*>(dst)[i] = h;
+    }
+}
+
+// frag32h [R][K] -> row-major fp32 (tests / debugging)
+static __global__ __launch_bounds__(256) void k_unpack_rows_h(const _Float16* __restrict__ src, float* __restrict__ dst, int R, int K) {
+    const int nch = K >> 5;
+    const size_t total = (size_t)((R + 15) / 16) * nch * 64;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int lane = (int)(i & 63);
+        const size_t blk = i >> 6;
+        const int rt = (int)(blk / nch), c = (int)(blk % nch);
+        const int r = rt * 16 + (lane & 15);
+        if (r < R) {
+            const f16x8 h = reinterpret_cast<const f16x8*>(src)[i];
+            float* p = dst + (size_t)r * K + c * 32 + 8 * (lane >> 4);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) p[j] = (float)h[j];
+        }
+    }
+}
 
 // row-major [R][K] -> frag16; rows R .. 16*ceil(R/16) are zero-filled.  One float4 per thread.
 static __global__ __launch_bounds__(256) void k_pack_rows(const float* __restrict__ src, float* __restrict__ dst, int R, int K) {
@@ -72,6 +123,10 @@ static __global__ __launch_bounds__(256) void k_unpack_rows(const float* __restr
     }
 }
 
+__device__ __forceinline__ f16x8 nd_as_h8(const float4& v) {   // the 16 bytes of a lane's operand, viewed as 8 halfs
+    return __builtin_bit_cast(f16x8, v);
+}
+
 template <bool NT>
 __device__ __forceinline__ float4 nd_ld16(const float* p) {
     if (NT) {
@@ -87,11 +142,11 @@ __device__ __forceinline__ float4 nd_ld16(const float* p) {
 //           -- lin3 + unetnorm3 + softplus + lin4 (latent_model.py:181-184) in one pass.
 //   MODE 2: split-K partial sums, no epilogue: part[slab, m, n] = sum_{k in slab} x[m,k] w[n,k]
 struct SkinnyDesc {
-    const float* x;      // frag16 [M][K]
+    const float* x;      // frag16 [M][K]   (frag32h in the fp16 kernels: opaque 1 KiB blocks either way)
     const float* w;      // frag16 [N][K]   (nn.Linear weight, rows padded to 16 with zeros)
     const float* scale;  // [rows, N] or nullptr (=1)
     const float* shift;  // [rows, N] or nullptr (=0)
-    float* out;          // MODE 0: frag16 [M][N] if out_packed else row-major [M][N]
+    float* out;          // MODE 0: out_packed 0 = row-major fp32 [M][N], 1 = frag16 fp32, 2 = frag32h fp16 (N % 32 == 0)
     const float* pw;     // [C, N]            (MODE 1)
     float* part;         // MODE 1: [M, C, ceil(N/16)];  MODE 2: [S, Mpad, Npad]
     int K, N, C, act, out_packed;
@@ -110,12 +165,13 @@ struct SkinnyDesc {
 // MFMA 16x16x4 f32: A[i=l&15][k=l>>4] <- W rows, B[k=l>>4][j=l&15] <- x rows, D[i=4*(l>>4)+r][j=l&15];
 // lane l's float4 holds k = 4*(l>>4)..+3 of a chunk and element jj feeds MFMA jj (same k permutation on
 // both operands).
-template <int MT, int NF, int WAVES, int U, int MODE, bool NT>
+// H = 1: operands are frag32h (fp16), one v_mfma_f32_16x16x32_f16 per fragment pair and 32-column chunk.
+template <int MT, int NF, int WAVES, int U, int MODE, bool NT, int H = 0>
 __global__ __launch_bounds__(WAVES * 64) void k_skinny(SkinnyDesc d0, const SkinnyDesc* __restrict__ table, int nm,
                                                        int M, int t, int cps) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int K = table ? table[0].K : d0.K, N = table ? table[0].N : d0.N;
-    const int nch = K >> 4, nfr = (N + 15) >> 4, total = nm * nfr, mtiles = (M + 15) >> 4;
+    const int nch = H ? K >> 5 : K >> 4, nfr = (N + 15) >> 4, total = nm * nfr, mtiles = (M + 15) >> 4;
     const int f0 = blockIdx.x * NF;
     const int c0 = MODE == 2 ? blockIdx.z * cps : 0;
     const int c1 = MODE == 2 ? min(c0 + cps, nch) : nch;
@@ -203,6 +259,15 @@ __global__ __launch_bounds__(WAVES * 64) void k_skinny(SkinnyDesc d0, const Skin
             // prefetch the next group (clamped: the last iteration re-reads a valid group, unused)
             const int gn = min(wave + (i + 1) * WAVES, glast);
             LDW(wn, gn); LDX(xn, xA, gn);
+            if (H) {
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int f = 0; f < NF; ++f)
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+                            acc[f][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(nd_as_h8(wc[u][f]), nd_as_h8(xc[u][mt]), acc[f][mt], 0, 0, 0);
+            } else {
 #pragma unroll
             for (int u = 0; u < U; ++u)
 #pragma unroll
@@ -216,6 +281,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_skinny(SkinnyDesc d0, const Skin
                             acc[f][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, xv, acc[f][mt], 0, 0, 0);
                         }
                     }
+            }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
 #pragma unroll
@@ -229,6 +295,18 @@ __global__ __launch_bounds__(WAVES * 64) void k_skinny(SkinnyDesc d0, const Skin
         for (int i = 0; i < ngw; ++i) {
             const int gn = wave + i * WAVES;
             LDW(wc, gn); LDX(xc, xA, gn); LDX(xb, xB, gn);
+            if (H) {
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int f = 0; f < NF; ++f) {
+                        const bool useB = gidx[f] != gA;
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+                            acc[f][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(nd_as_h8(wc[u][f]), nd_as_h8(useB ? xb[u][mt] : xc[u][mt]),
+                                                                                acc[f][mt], 0, 0, 0);
+                    }
+            } else {
 #pragma unroll
             for (int u = 0; u < U; ++u)
 #pragma unroll
@@ -244,6 +322,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_skinny(SkinnyDesc d0, const Skin
                             acc[f][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, useB ? xv : xa, acc[f][mt], 0, 0, 0);
                         }
                     }
+            }
         }
     }
     // leftover chunks (chunk count not a multiple of U): chunk c goes to wave c % WAVES
@@ -257,8 +336,11 @@ __global__ __launch_bounds__(WAVES * 64) void k_skinny(SkinnyDesc d0, const Skin
             for (int mt = 0; mt < MT; ++mt) {
                 const float4 x4 = *reinterpret_cast<const float4*>((useB ? xB[mt] : xA[mt]) + (size_t)c * 256);
                 const float xv[4] = {x4.x, x4.y, x4.z, x4.w};
+                if (H) acc[f][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(nd_as_h8(w4), nd_as_h8(x4), acc[f][mt], 0, 0, 0);
+                else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[f][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[j], xv[j], acc[f][mt], 0, 0, 0);
+                    for (int j = 0; j < 4; ++j) acc[f][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[j], xv[j], acc[f][mt], 0, 0, 0);
+                }
             }
         }
     }
@@ -314,7 +396,22 @@ __global__ __launch_bounds__(WAVES * 64) void k_skinny(SkinnyDesc d0, const Skin
                 const int m0 = blockIdx.y * 16 * MT;
                 if (MODE == 0) {
                     float* outp = table ? table[g].out : d0.out;
-                    if (epacked) {
+                    if (epacked == 2) {
+                        // frag32h: this fragment's 16 columns are k-groups (nfi&1)*2 + {0,1} of block (m-tile, nfi/2): lanes
+                        // 32*(nfi&1) .. +31 of it, 512 contiguous bytes per m-tile
+                        _Float16* outh = reinterpret_cast<_Float16*>(outp);
+                        const int nch_o = N >> 5;
+                        for (int e = tid; e < MT * 32; e += WAVES * 64) {
+                            const int mt = e >> 5, L = e & 31;
+                            const int mtg = blockIdx.y * MT + mt;
+                            if (mtg < mtiles) {
+                                const float* tp = &tile[16 * mt + (L & 15)][8 * (L >> 4)];
+                                const f16x8 h = {(_Float16)tp[0], (_Float16)tp[1], (_Float16)tp[2], (_Float16)tp[3],
+                                                 (_Float16)tp[4], (_Float16)tp[5], (_Float16)tp[6], (_Float16)tp[7]};
+                                *reinterpret_cast<f16x8*>(outh + ((size_t)mtg * nch_o + (nfi >> 1)) * 512 + ((nfi & 1) * 32 + L) * 8) = h;
+                            }
+                        }
+                    } else if (epacked) {
                         // the 16x16 block (m-tile, this fragment) is one contiguous 1 KiB of the frag16 output
                         for (int e = tid; e < MT * 64; e += WAVES * 64) {
                             const int mt = e >> 6, L = e & 63;
@@ -379,7 +476,10 @@ static __global__ __launch_bounds__(256) void k_splitk_epilogue(SplitKEpiDesc d0
         const float b = d.shift ? d.shift[nn] : 0.0f;
         o[r] = (n + r < N) ? nd_act(a * o[r] + b, d.act) : 0.f;
     }
-    if (d.out_packed) {
+    if (d.out_packed == 2) {
+        *reinterpret_cast<f16x4*>(reinterpret_cast<_Float16*>(d.out) + nd_pkh(m, n, N >> 5)) =
+            f16x4{(_Float16)o[0], (_Float16)o[1], (_Float16)o[2], (_Float16)o[3]};
+    } else if (d.out_packed) {
         *reinterpret_cast<float4*>(d.out + nd_pk(m, n, N >> 4)) = make_float4(o[0], o[1], o[2], o[3]);
     } else if (m < M) {
 #pragma unroll
@@ -398,9 +498,9 @@ struct SkinnyLaunch { void* fn; dim3 grid; dim3 block; int cps; int S; };
 // the 256 MiB Infinity Cache keeps across consecutive steps are streamed with nontemporal loads.
 // MODE 2 (split-K): S k-slabs in grid.z so that (fragment groups) x (row groups) x S >= 1024 workgroups.
 template <int MODE>
-static inline SkinnyLaunch nd_skinny_launch(int K, int N, int M, int nm) {
+static inline SkinnyLaunch nd_skinny_launch(int K, int N, int M, int nm, int half = 0) {
     const int mt = nd_pick_mt(M);
-    const int nfr = (N + 15) / 16, total = nm * nfr, nch = K / 16;
+    const int nfr = (N + 15) / 16, total = nm * nfr, nch = half ? K / 32 : K / 16;
     const int mgroups = (M + 16 * mt - 1) / (16 * mt);
     const int nfmax = mt == 4 ? 2 : 5;
     int nf = total / 256;
@@ -416,9 +516,11 @@ static inline SkinnyLaunch nd_skinny_launch(int K, int N, int M, int nm) {
         cps = (nch + S - 1) / S;
         S = (nch + cps - 1) / cps;
     }
-    const bool nt = (double)nm * N * (double)K * 4.0 > 160e6;
+    const bool nt = (double)nm * N * (double)K * (half ? 2.0 : 4.0) > 160e6;
     SkinnyLaunch L{nullptr, dim3((total + nf - 1) / nf, mgroups, S), dim3(mt == 4 ? 512 : 1024), cps, S};
-#define ND_SK(MTV, NFV, WV, UV) (nt ? (void*)k_skinny<MTV, NFV, WV, UV, MODE, true> : (void*)k_skinny<MTV, NFV, WV, UV, MODE, false>)
+#define ND_SK(MTV, NFV, WV, UV)                                                                                     \
+    (half ? (nt ? (void*)k_skinny<MTV, NFV, WV, UV, MODE, true, 1> : (void*)k_skinny<MTV, NFV, WV, UV, MODE, false, 1>) \
+          : (nt ? (void*)k_skinny<MTV, NFV, WV, UV, MODE, true, 0> : (void*)k_skinny<MTV, NFV, WV, UV, MODE, false, 0>))
     if (mt == 4) {
         L.fn = nf == 1 ? ND_SK(4, 1, 8, 2) : ND_SK(4, 2, 8, 2);
     } else if (mt == 2) {
@@ -442,8 +544,8 @@ static inline SkinnyLaunch nd_skinny_launch(int K, int N, int M, int nm) {
     return L;
 }
 
-static inline size_t nd_splitk_part_floats(int M, int K, int N, int nm = 1) {
-    const SkinnyLaunch L = nd_skinny_launch<2>(K, N, M, nm);
+static inline size_t nd_splitk_part_floats(int M, int K, int N, int nm = 1, int half = 0) {
+    const SkinnyLaunch L = nd_skinny_launch<2>(K, N, M, nm, half);
     return (size_t)L.S * (size_t)(((M + 15) / 16) * 16) * (size_t)(((N + 15) / 16) * 16);
 }
 

@@ -12,50 +12,63 @@ int nd_set_err(int code, const char* fmt, ...);
     } while (0)
 
 // ---- packing ---------------------------------------------------------------------------------
-extern "C" size_t nd_packed_bytes(int R, int K) {
-    if (R < 1 || K < 16 || (K % 16)) return 0;
-    return nd_packed_floats(R, K) * sizeof(float);
+static int bad_dtype(int dtype) { return dtype != ND_DTYPE_F32 && dtype != ND_DTYPE_F16; }
+static int kmul(int dtype) { return dtype == ND_DTYPE_F16 ? 32 : 16; }
+
+extern "C" size_t nd_packed_bytes(int R, int K, int dtype) {
+    if (bad_dtype(dtype) || R < 1 || K < kmul(dtype) || (K % kmul(dtype))) return 0;
+    return nd_packed_bytes_dt(R, K, dtype == ND_DTYPE_F16);
 }
 
-extern "C" int nd_pack_rows(const float* src, float* dst, int R, int K, void* stream) {
+extern "C" int nd_pack_rows(const float* src, void* dst, int R, int K, int dtype, void* stream) {
     if (!src || !dst) return nd_set_err(ND_ERR_ARG, "NULL tensor");
-    if (R < 1 || K < 16 || (K % 16)) return nd_set_err(ND_ERR_ARG, "need R >= 1 and K a positive multiple of 16 (K=%d)", K);
-    const size_t n4 = nd_packed_floats(R, K) / 4, want = (n4 + 255) / 256;
-    hipLaunchKernelGGL(k_pack_rows, dim3((unsigned)(want > 8192 ? 8192 : want)), dim3(256), 0, (hipStream_t)stream, src, dst, R, K);
+    if (bad_dtype(dtype)) return nd_set_err(ND_ERR_ARG, "unknown dtype %d", dtype);
+    if (R < 1 || K < kmul(dtype) || (K % kmul(dtype)))
+        return nd_set_err(ND_ERR_ARG, "need R >= 1 and K a positive multiple of %d (K=%d)", kmul(dtype), K);
+    const int half = dtype == ND_DTYPE_F16;
+    const size_t n16 = nd_packed_bytes_dt(R, K, half) / 16, want = (n16 + 255) / 256;
+    const dim3 grid((unsigned)(want > 8192 ? 8192 : want));
+    if (half) hipLaunchKernelGGL(k_pack_rows_h, grid, dim3(256), 0, (hipStream_t)stream, src, (_Float16*)dst, R, K);
+    else hipLaunchKernelGGL(k_pack_rows, grid, dim3(256), 0, (hipStream_t)stream, src, (float*)dst, R, K);
     HIP_CHECK(hipGetLastError());
     return ND_OK;
 }
 
 // ---- nd_linear: mapping/models/mlp.py:25-28 ---------------------------------------------------
-extern "C" size_t nd_linear_workspace_bytes(int M, int K, int N) {
-    if (M < 1 || K < 16 || (K % 16) || N < 1) return 0;
-    size_t fl = nd_packed_floats(M, K) + 64;
-    if (nd_use_splitk(K)) fl += nd_splitk_part_floats(M, K, N);
-    return fl * sizeof(float) + 256;
+extern "C" size_t nd_linear_workspace_bytes(int M, int K, int N, int dtype) {
+    if (bad_dtype(dtype) || M < 1 || K < kmul(dtype) || (K % kmul(dtype)) || N < 1) return 0;
+    const int half = dtype == ND_DTYPE_F16;
+    size_t bytes = nd_packed_bytes_dt(M, K, half) + 256;
+    if (nd_use_splitk(K)) bytes += nd_splitk_part_floats(M, K, N, 1, half) * sizeof(float);
+    return bytes + 256;
 }
 
-extern "C" int nd_linear(const float* x, const float* wpk, const float* scale, const float* shift, float* out, int M, int K, int N,
-                         int act, void* ws, size_t ws_bytes, void* stream) {
+extern "C" int nd_linear(const float* x, const void* wpk, const float* scale, const float* shift, float* out, int M, int K, int N,
+                         int act, int dtype, void* ws, size_t ws_bytes, void* stream) {
     if (!x || !wpk || !out) return nd_set_err(ND_ERR_ARG, "NULL tensor");
-    if (M < 1 || N < 1 || K < 16 || (K % 16)) return nd_set_err(ND_ERR_ARG, "need M,N >= 1 and K a positive multiple of 16 (K=%d)", K);
+    if (bad_dtype(dtype)) return nd_set_err(ND_ERR_ARG, "unknown dtype %d", dtype);
+    if (M < 1 || N < 1 || K < kmul(dtype) || (K % kmul(dtype)))
+        return nd_set_err(ND_ERR_ARG, "need M,N >= 1 and K a positive multiple of %d (K=%d)", kmul(dtype), K);
     if (act < 0 || act > 3) return nd_set_err(ND_ERR_ARG, "unknown activation %d", act);
-    const size_t need = nd_linear_workspace_bytes(M, K, N);
+    const size_t need = nd_linear_workspace_bytes(M, K, N, dtype);
     if (!ws || ws_bytes < need) return nd_set_err(ND_ERR_ARG, "workspace too small: %zu < %zu", ws_bytes, need);
+    const int half = dtype == ND_DTYPE_F16;
     hipStream_t st = (hipStream_t)stream;
     float* xpk = (float*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
-    float* part = xpk + nd_packed_floats(M, K) + 64;
-    int rc = nd_pack_rows(x, xpk, M, K, stream);
+    float* part = (float*)((char*)xpk + ((nd_packed_bytes_dt(M, K, half) + 255) & ~(size_t)255));
+    int rc = nd_pack_rows(x, xpk, M, K, dtype, stream);
     if (rc != ND_OK) return rc;
+    const float* wf = (const float*)wpk;     // opaque 1 KiB operand blocks in either dtype
     if (nd_use_splitk(K)) {
-        const SkinnyLaunch L = nd_skinny_launch<2>(K, N, M, 1);
-        SkinnyDesc sd{xpk, wpk, nullptr, nullptr, nullptr, nullptr, part, K, N, 0, ND_ACT_NONE, 0};
+        const SkinnyLaunch L = nd_skinny_launch<2>(K, N, M, 1, half);
+        SkinnyDesc sd{xpk, wf, nullptr, nullptr, nullptr, nullptr, part, K, N, 0, ND_ACT_NONE, 0};
         HIP_CHECK(nd_launch_skinny(L, sd, nullptr, 1, M, 0, st));
         SplitKEpiDesc se{part, scale, shift, out, N, L.S, act, 0};
         const size_t q = (size_t)(((M + 15) / 16) * 16) * (((N + 15) / 16) * 16) / 4;
         hipLaunchKernelGGL(k_splitk_epilogue, dim3((unsigned)((q + 255) / 256)), dim3(256), 0, st, se, (const SplitKEpiDesc*)nullptr, M, L.S);
     } else {
-        SkinnyDesc d{xpk, wpk, scale, shift, out, nullptr, nullptr, K, N, 0, act, 0};
-        HIP_CHECK(nd_launch_skinny(nd_skinny_launch<0>(K, N, M, 1), d, nullptr, 1, M, 0, st));
+        SkinnyDesc d{xpk, wf, scale, shift, out, nullptr, nullptr, K, N, 0, act, 0};
+        HIP_CHECK(nd_launch_skinny(nd_skinny_launch<0>(K, N, M, 1, half), d, nullptr, 1, M, 0, st));
     }
     HIP_CHECK(hipGetLastError());
     return ND_OK;

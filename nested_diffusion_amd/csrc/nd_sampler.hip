@@ -50,6 +50,7 @@ struct MemberDev {
     float* h1;             // frag16 [M, F]
     float* ybuf;           // [2, maxM, C]
     const float* epart;    // [M, C, NT]
+    int h16;               // 1: h1 is written as frag32h fp16
 };
 
 #define ND_MAX_C 8
@@ -200,7 +201,11 @@ __global__ __launch_bounds__(256) void k_step_head(const MemberDev* __restrict__
     h.y = nd_softplus(a.y * u[1] + cc.y) * xe.y;
     h.z = nd_softplus(a.z * u[2] + cc.z) * xe.z;
     h.w = nd_softplus(a.w * u[3] + cc.w) * xe.w;
-    *reinterpret_cast<float4*>(mb.h1 + nd_pk(m, n, nchF)) = h;
+    if (mb.h16)
+        *reinterpret_cast<f16x4*>(reinterpret_cast<_Float16*>(mb.h1) + nd_pkh(m, n, F >> 5)) =
+            f16x4{(_Float16)h.x, (_Float16)h.y, (_Float16)h.z, (_Float16)h.w};
+    else
+        *reinterpret_cast<float4*>(mb.h1 + nd_pk(m, n, nchF)) = h;
 }
 
 static void* head_fn(int C) {
@@ -327,6 +332,7 @@ struct nd_handle_s {
     int sched_T = 0;
     int NT = 0, S0 = 0;
     bool enc_splitk = false;
+    int half = 0;                          // cfg.operand_dtype == ND_DTYPE_F16
     std::map<GraphKey, hipGraphExec_t> graphs;
     int encoded_B = -1;
     bool profiling = false;
@@ -351,8 +357,10 @@ static void carve(nd_handle_s* h, char* base, size_t* total) {
     const size_t mB = c.max_batch, mM = c.max_rows;
     const size_t pB = ((mB + 15) / 16) * 16, pM = ((mM + 15) / 16) * 16;   // rows padded to whole 16-row tiles
     h->NT = (int)((F + 15) / 16);
+    h->half = c.operand_dtype == ND_DTYPE_F16;
+    const size_t wdiv = h->half ? 2 : 1;                                     // packed weights: floats -> halfs
     h->enc_splitk = nd_use_splitk(c.data_dim);
-    h->S0 = h->enc_splitk ? nd_skinny_launch<2>(c.data_dim, c.hidden_dim, c.max_batch, 1).S : 0;
+    h->S0 = h->enc_splitk ? nd_skinny_launch<2>(c.data_dim, c.hidden_dim, c.max_batch, 1, h->half).S : 0;
     Carver cv{base};
     h->members_dev = cv.take<MemberDev>(K);
     h->descs_dev = cv.take<SkinnyDesc>(L_COUNT * K);
@@ -367,8 +375,8 @@ static void carve(nd_handle_s* h, char* base, size_t* total) {
         m.sc1 = cv.take<float>(H); m.sh1 = cv.take<float>(H);
         m.sc2 = cv.take<float>(F); m.sh2 = cv.take<float>(F);
         for (int l = 0; l < 3; ++l) { m.A[l] = cv.take<float>(T * F); m.Cc[l] = cv.take<float>(T * F); }
-        m.w_enc0 = cv.take<float>(H * D); m.w_enc3 = cv.take<float>(H * H); m.w_enc6 = cv.take<float>(F * H);
-        m.w_lin2 = cv.take<float>(F * F); m.w_lin3 = cv.take<float>(F * F);
+        m.w_enc0 = cv.take<float>(H * D / wdiv); m.w_enc3 = cv.take<float>(H * H / wdiv); m.w_enc6 = cv.take<float>(F * H / wdiv);
+        m.w_lin2 = cv.take<float>(F * F / wdiv); m.w_lin3 = cv.take<float>(F * F / wdiv);
         m.w_lin1 = cv.take<float>(F * 2 * C); m.w_lin4 = cv.take<float>(C * F); m.b_lin4 = cv.take<float>(C);
         m.e0 = cv.take<float>(pB * H); m.e1 = cv.take<float>(pB * H); m.xe = cv.take<float>(pB * F);
         m.ybuf = cv.take<float>(2 * mM * C);
@@ -387,6 +395,10 @@ static int check_cfg(const nd_config* c) {
     if (c->hidden_dim < 16 || c->hidden_dim % 16) return nd_set_err(ND_ERR_ARG, "hidden_dim must be a positive multiple of 16");
     if (c->feature_dim < 16 || c->feature_dim % 16) return nd_set_err(ND_ERR_ARG, "feature_dim must be a positive multiple of 16");
     if (c->n_steps < 1) return nd_set_err(ND_ERR_ARG, "n_steps must be >= 1");
+    if (c->operand_dtype != ND_DTYPE_F32 && c->operand_dtype != ND_DTYPE_F16)
+        return nd_set_err(ND_ERR_ARG, "operand_dtype must be ND_DTYPE_F32 or ND_DTYPE_F16");
+    if (c->operand_dtype == ND_DTYPE_F16 && ((c->data_dim | c->hidden_dim | c->feature_dim) % 32))
+        return nd_set_err(ND_ERR_ARG, "fp16 operands need data_dim, hidden_dim and feature_dim to be multiples of 32");
     if (c->n_members < 1 || c->max_batch < 1 || c->max_rows < c->max_batch)
         return nd_set_err(ND_ERR_ARG, "n_members/max_batch/max_rows invalid");
     return ND_OK;
@@ -453,10 +465,12 @@ extern "C" int nd_set_schedule(nd_handle h, const float* alphas_dev, const float
     return ND_OK;
 }
 
-static void launch_pack(const float* src, float* dst, int R, int K, hipStream_t st) {
-    const size_t n4 = (size_t)((R + 15) / 16) * 16 * K / 4;
+static void launch_pack(const float* src, float* dst, int R, int K, int half, hipStream_t st) {
+    const size_t n4 = (size_t)((R + 15) / 16) * 16 * K / (half ? 8 : 4);
     const size_t want = (n4 + 255) / 256;
-    hipLaunchKernelGGL(k_pack_rows, dim3((unsigned)(want > 8192 ? 8192 : want)), dim3(256), 0, st, src, dst, R, K);
+    const dim3 grid((unsigned)(want > 8192 ? 8192 : want));
+    if (half) hipLaunchKernelGGL(k_pack_rows_h, grid, dim3(256), 0, st, src, reinterpret_cast<_Float16*>(dst), R, K);
+    else hipLaunchKernelGGL(k_pack_rows, grid, dim3(256), 0, st, src, dst, R, K);
 }
 
 extern "C" int nd_load_member(nd_handle h, int k, const nd_member_weights* w, void* stream) {
@@ -485,22 +499,23 @@ extern "C" int nd_load_member(nd_handle h, int k, const nd_member_weights* w, vo
         hipLaunchKernelGGL(k_fold_steps, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, m.A[l], m.Cc[l], embs[l], lb[l],
                            bw[l], bb[l], bm[l], bv[l], T, F);
     // weights -> frag16 in the workspace; the raw tensors are not referenced after this call returns
-    launch_pack(w->enc0_w, m.w_enc0, H, D, st);
-    launch_pack(w->enc3_w, m.w_enc3, H, H, st);
-    launch_pack(w->enc6_w, m.w_enc6, F, H, st);
-    launch_pack(w->lin2_w, m.w_lin2, F, F, st);
-    launch_pack(w->lin3_w, m.w_lin3, F, F, st);
+    launch_pack(w->enc0_w, m.w_enc0, H, D, h->half, st);
+    launch_pack(w->enc3_w, m.w_enc3, H, H, h->half, st);
+    launch_pack(w->enc6_w, m.w_enc6, F, H, h->half, st);
+    launch_pack(w->lin2_w, m.w_lin2, F, F, h->half, st);
+    launch_pack(w->lin3_w, m.w_lin3, F, F, h->half, st);
     HIP_CHECK(hipMemcpyAsync(m.w_lin1, w->lin1_w, sizeof(float) * F * 2 * C, hipMemcpyDeviceToDevice, st));
     HIP_CHECK(hipMemcpyAsync(m.w_lin4, w->lin4_w, sizeof(float) * C * F, hipMemcpyDeviceToDevice, st));
     HIP_CHECK(hipMemcpyAsync(m.b_lin4, w->lin4_b, sizeof(float) * C, hipMemcpyDeviceToDevice, st));
     HIP_CHECK(hipGetLastError());
 
-    MemberDev md{m.w_lin1, m.b_lin4, m.A[0], m.Cc[0], m.xe, m.h1, m.ybuf, m.epart};
+    MemberDev md{m.w_lin1, m.b_lin4, m.A[0], m.Cc[0], m.xe, m.h1, m.ybuf, m.epart, h->half};
+    const int opk = h->half ? 2 : 1;     // layout of an activation that feeds the next GEMM
     SkinnyDesc ds[L_COUNT];
-    ds[L_ENC0] = SkinnyDesc{h->xpack, m.w_enc0, m.sc0, m.sh0, m.e0, nullptr, nullptr, D, H, C, ND_ACT_SOFTPLUS, 1};
-    ds[L_ENC1] = SkinnyDesc{m.e0, m.w_enc3, m.sc1, m.sh1, m.e1, nullptr, nullptr, H, H, C, ND_ACT_SOFTPLUS, 1};
+    ds[L_ENC0] = SkinnyDesc{h->xpack, m.w_enc0, m.sc0, m.sh0, m.e0, nullptr, nullptr, D, H, C, ND_ACT_SOFTPLUS, opk};
+    ds[L_ENC1] = SkinnyDesc{m.e0, m.w_enc3, m.sc1, m.sh1, m.e1, nullptr, nullptr, H, H, C, ND_ACT_SOFTPLUS, opk};
     ds[L_ENC2] = SkinnyDesc{m.e1, m.w_enc6, m.sc2, m.sh2, m.xe, nullptr, nullptr, H, F, C, ND_ACT_NONE, 1};
-    ds[L_LIN2] = SkinnyDesc{m.h1, m.w_lin2, m.A[1], m.Cc[1], m.h2, nullptr, nullptr, F, F, C, ND_ACT_SOFTPLUS, 1};
+    ds[L_LIN2] = SkinnyDesc{m.h1, m.w_lin2, m.A[1], m.Cc[1], m.h2, nullptr, nullptr, F, F, C, ND_ACT_SOFTPLUS, opk};
     ds[L_LIN3] = SkinnyDesc{m.h2, m.w_lin3, m.A[2], m.Cc[2], nullptr, m.w_lin4, m.epart, F, F, C, ND_ACT_SOFTPLUS, 0};
     // small synchronous H2D copies: load time only, never on the sampling path.  The sync also means the
     // caller may release its raw weight tensors as soon as this function returns.
@@ -510,7 +525,7 @@ extern "C" int nd_load_member(nd_handle h, int k, const nd_member_weights* w, vo
         HIP_CHECK(hipMemcpy(h->descs_dev + (size_t)l * c.n_members + k, &ds[l], sizeof(SkinnyDesc), hipMemcpyHostToDevice));
     if (h->enc_splitk) {
         SkinnyDesc sd{h->xpack, m.w_enc0, nullptr, nullptr, nullptr, nullptr, m.splitk, D, H, C, ND_ACT_NONE, 0};
-        SplitKEpiDesc se{m.splitk, m.sc0, m.sh0, m.e0, H, 0 /* S is a launch argument */, ND_ACT_SOFTPLUS, 1};
+        SplitKEpiDesc se{m.splitk, m.sc0, m.sh0, m.e0, H, 0 /* S is a launch argument */, ND_ACT_SOFTPLUS, opk};
         HIP_CHECK(hipMemcpy(h->spk_dev + k, &sd, sizeof sd, hipMemcpyHostToDevice));
         HIP_CHECK(hipMemcpy(h->spke_dev + k, &se, sizeof se, hipMemcpyHostToDevice));
     }
@@ -528,8 +543,8 @@ static int check_range(nd_handle_s* h, int m0, int nm) {
 }
 
 template <int MODE>
-static hipError_t launch_skinny(const SkinnyDesc* table, int K, int N, int M, int t, int nm, hipStream_t st) {
-    return nd_launch_skinny(nd_skinny_launch<MODE>(K, N, M, nm), SkinnyDesc{}, table, nm, M, t, st);
+static hipError_t launch_skinny(const SkinnyDesc* table, int K, int N, int M, int t, int nm, int half, hipStream_t st) {
+    return nd_launch_skinny(nd_skinny_launch<MODE>(K, N, M, nm, half), SkinnyDesc{}, table, nm, M, t, st);
 }
 
 extern "C" int nd_encode(nd_handle h, int m0, int nm, const float* x_dev, int B, void* stream) {
@@ -540,18 +555,18 @@ extern "C" int nd_encode(nd_handle h, int m0, int nm, const float* x_dev, int B,
     hipStream_t st = (hipStream_t)stream;
     const nd_config& c = h->cfg;
     const int K = c.n_members, H = c.hidden_dim, F = c.feature_dim, D = c.data_dim;
-    launch_pack(x_dev, h->xpack, B, D, st);       // images -> frag16 once; every member reads the same batch
+    launch_pack(x_dev, h->xpack, B, D, h->half, st);       // images -> frag16 once; every member reads the same batch
     if (h->enc_splitk) {
-        const SkinnyLaunch L = nd_skinny_launch<2>(D, H, B, nm);
+        const SkinnyLaunch L = nd_skinny_launch<2>(D, H, B, nm, h->half);
         HIP_CHECK(nd_launch_skinny(L, SkinnyDesc{}, h->spk_dev + m0, nm, B, 0, st));
         const size_t q = (size_t)(((B + 15) / 16) * 16) * H / 4;
         hipLaunchKernelGGL(k_splitk_epilogue, dim3((unsigned)((q + 255) / 256), 1, nm), dim3(256), 0, st, SplitKEpiDesc{},
                            (const SplitKEpiDesc*)(h->spke_dev + m0), B, L.S);
     } else {
-        HIP_CHECK(launch_skinny<0>(h->descs_dev + (size_t)L_ENC0 * K + m0, D, H, B, 0, nm, st));
+        HIP_CHECK(launch_skinny<0>(h->descs_dev + (size_t)L_ENC0 * K + m0, D, H, B, 0, nm, h->half, st));
     }
-    HIP_CHECK(launch_skinny<0>(h->descs_dev + (size_t)L_ENC1 * K + m0, H, H, B, 0, nm, st));
-    HIP_CHECK(launch_skinny<0>(h->descs_dev + (size_t)L_ENC2 * K + m0, H, F, B, 0, nm, st));
+    HIP_CHECK(launch_skinny<0>(h->descs_dev + (size_t)L_ENC1 * K + m0, H, H, B, 0, nm, h->half, st));
+    HIP_CHECK(launch_skinny<0>(h->descs_dev + (size_t)L_ENC2 * K + m0, H, F, B, 0, nm, h->half, st));
     HIP_CHECK(hipGetLastError());
     h->encoded_B = B;
     return ND_OK;
@@ -567,7 +582,11 @@ extern "C" int nd_member_buffer(nd_handle h, int k, int which, float* dst_dev, i
     if (which == 0 && rows > h->cfg.max_batch) return nd_set_err(ND_ERR_ARG, "xe holds at most max_batch rows");
     const int F = h->cfg.feature_dim;
     const size_t n4 = (size_t)((rows + 15) / 16) * 16 * F / 4;
-    hipLaunchKernelGGL(k_unpack_rows, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, dst_dev, rows, F);
+    if (h->half && which != 0)   // h1/h2 are GEMM operands (fp16 in that mode); xe never is
+        hipLaunchKernelGGL(k_unpack_rows_h, dim3((unsigned)((n4 / 2 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                           reinterpret_cast<const _Float16*>(src), dst_dev, rows, F);
+    else
+        hipLaunchKernelGGL(k_unpack_rows, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, dst_dev, rows, F);
     HIP_CHECK(hipGetLastError());
     return ND_OK;
 }
@@ -613,8 +632,8 @@ static int single_eval(nd_handle_s* h, int member, StepIO io, int t, int final_m
         void* ah[] = {&mdev, &io, &mode, &istep, &tprev, &tt, &Bv, &Mv, &maxM, &Fv, &NT, &Tn};
         HIP_CHECK(hipLaunchKernel(head_fn(C), dim3((F + 1023) / 1024, M, 1), dim3(256), ah, 0, st));
     }
-    HIP_CHECK(launch_skinny<0>(h->descs_dev + (size_t)L_LIN2 * K + member, F, F, M, t, 1, st));
-    HIP_CHECK(launch_skinny<1>(h->descs_dev + (size_t)L_LIN3 * K + member, F, F, M, t, 1, st));
+    HIP_CHECK(launch_skinny<0>(h->descs_dev + (size_t)L_LIN2 * K + member, F, F, M, t, 1, h->half, st));
+    HIP_CHECK(launch_skinny<1>(h->descs_dev + (size_t)L_LIN3 * K + member, F, F, M, t, 1, h->half, st));
     {
         const MemberDev* mdev = h->members_dev + member;
         int fm = final_mode, tt = t, Bv = B, Mv = M, maxM = c.max_rows, NT = h->NT, Tn = c.n_steps;
@@ -691,7 +710,7 @@ static hipError_t emit_loop(nd_handle_s* h, Emitter& em, int m0, int nm, StepIO 
     const SkinnyDesc* t3 = h->descs_dev + (size_t)L_LIN3 * K + m0;
     SkinnyDesc d0{};
     const dim3 ghead((F + 1023) / 1024, M, nm);
-    const SkinnyLaunch L2 = nd_skinny_launch<0>(F, F, M, nm), L3 = nd_skinny_launch<1>(F, F, M, nm);
+    const SkinnyLaunch L2 = nd_skinny_launch<0>(F, F, M, nm, h->half), L3 = nd_skinny_launch<1>(F, F, M, nm, h->half);
     int cps2 = L2.cps, cps3 = L3.cps;
     // probes: up to 8 steps spread over the loop (never step 0: its head is the cheap INIT form)
     const int want = h->profiling ? (T - 1 < 8 ? T - 1 : 8) : 0;

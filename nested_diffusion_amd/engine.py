@@ -27,11 +27,14 @@ class EnsembleEngine:
     """
 
     def __init__(self, y_dim: int, data_dim: int, hidden_dim: int, feature_dim: int, n_steps: int,
-                 n_members: int = 1, max_batch: int = 32, max_rows: Optional[int] = None, device="cuda"):
+                 n_members: int = 1, max_batch: int = 32, max_rows: Optional[int] = None, device="cuda", dtype="f32"):
+        """dtype 'f32': the reference's arithmetic.  'f16': the five large weight matrices and their input
+        activations in fp16 (fp32 accumulation / epilogues / state) -- BASELINE config 5, not a reference mode."""
         self.device = _require_gpu(device)
         self.lib = _lib.load()
         max_rows = max_rows if max_rows is not None else max_batch
-        self.cfg = NdConfig(y_dim, data_dim, hidden_dim, feature_dim, n_steps, n_members, max_batch, max_rows)
+        self.dtype = _lib.dtype_code(dtype)
+        self.cfg = NdConfig(y_dim, data_dim, hidden_dim, feature_dim, n_steps, n_members, max_batch, max_rows, self.dtype)
         self.C, self.D, self.H, self.F, self.T, self.K = y_dim, data_dim, hidden_dim, feature_dim, n_steps, n_members
         self.max_batch, self.max_rows = max_batch, max_rows
         h = C.c_void_p()

@@ -29,6 +29,8 @@ def build_parser() -> argparse.ArgumentParser:
     p = argparse.ArgumentParser(description="nested-diffusion inference on MI355X (reference-compatible CLI)")
     p.add_argument('--low_mem_mode', type=bool, required=False, default=False)      # quirk Q9: any non-empty string is True
     p.add_argument('--calib', action="store_true")
+    p.add_argument('--fp16', action="store_true",
+                   help="(not a reference flag) hold the large weight matrices and their input activations in fp16")
     p.add_argument('--mlp_idx', type=int, required=False)
     p.add_argument('--seed', type=int, required=False)
     p.add_argument('--preprocess', type=str, choices=['grayscaled', 'standardized'], required=True)

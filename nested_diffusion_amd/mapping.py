@@ -27,7 +27,7 @@ class Classifier:
 
     KEYS = [f"linear{i}.{s}" for i in range(1, 5) for s in ("weight", "bias")]
 
-    def __init__(self, state_dict: Dict[str, torch.Tensor], device="cuda"):
+    def __init__(self, state_dict: Dict[str, torch.Tensor], device="cuda", dtype="f32"):
         missing = [k for k in self.KEYS if k not in state_dict]
         if missing:
             raise KeyError(f"Classifier state_dict is missing {missing}")
@@ -37,7 +37,7 @@ class Classifier:
         for k in self.KEYS:
             t = state_dict[k].detach().to(self.device, torch.float32).contiguous()
             # weights are repacked once into the streaming kernels' fragment order; the row-major copy is dropped
-            self.p[k] = ops.PackedWeight(t) if k.endswith("weight") else t
+            self.p[k] = ops.PackedWeight(t, dtype) if k.endswith("weight") else t
 
     def __call__(self, x: torch.Tensor, dataset: str = "any") -> torch.Tensor:
         return self.forward(x, dataset)
@@ -163,12 +163,12 @@ def load_pickled(path: str) -> Dict[str, torch.Tensor]:
     return _to_state_dict(obj)
 
 
-def load_conditioner(trained_path: str, dataset: str, device="cuda", num_heads: int = 12) -> GuidingConditioner:
+def load_conditioner(trained_path: str, dataset: str, device="cuda", num_heads: int = 12, dtype="f32") -> GuidingConditioner:
     """classification_train_separately.py:252-275: <path>/vit_base_patch16_224_<Dataset>.pth and every
     file of sorted(os.listdir(<path>/MLPs))."""
     if trained_path not in sys.path:
         sys.path.append(trained_path)                      # so the pickled `mlp.Classifier` resolves (:255)
     vit_sd = load_pickled(os.path.join(trained_path, f"vit_base_patch16_224_{dataset}.pth"))
     mlp_dir = os.path.join(trained_path, "MLPs")
-    mlps = [Classifier(load_pickled(os.path.join(mlp_dir, f)), device) for f in sorted(os.listdir(mlp_dir))]
+    mlps = [Classifier(load_pickled(os.path.join(mlp_dir, f)), device, dtype) for f in sorted(os.listdir(mlp_dir))]
     return GuidingConditioner(VisionTransformer(vit_sd, num_heads, device), mlps)

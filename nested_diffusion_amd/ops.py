@@ -37,17 +37,20 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
 
 
 class PackedWeight:
-    """An nn.Linear weight [N, K] repacked once into the fragment order the streaming kernels read."""
+    """An nn.Linear weight [N, K] repacked once into the fragment order the streaming kernels read.
+    dtype 'f16': the fp16-operand image (half the bytes; K % 32 == 0) -- the fp16 mode, not the reference's arithmetic."""
 
-    def __init__(self, weight: torch.Tensor):
+    def __init__(self, weight: torch.Tensor, dtype="f32"):
         lib = _lib.load()
         weight = _f32(weight, "weight")
         self.N, self.K = weight.shape
-        nbytes = lib.nd_packed_bytes(self.N, self.K)
+        self.dtype = _lib.dtype_code(dtype)
+        nbytes = lib.nd_packed_bytes(self.N, self.K, self.dtype)
         if nbytes == 0:
-            raise _lib.NdError(f"cannot pack a [{self.N}, {self.K}] weight: K must be a positive multiple of 16")
+            raise _lib.NdError(f"cannot pack a [{self.N}, {self.K}] weight: K must be a positive multiple of "
+                               f"{32 if self.dtype == _lib.ND_DTYPE_F16 else 16}")
         self.data = torch.empty(nbytes // 4, dtype=torch.float32, device=weight.device)
-        check(lib.nd_pack_rows(ptr(weight), ptr(self.data), self.N, self.K, _stream(weight)), "nd_pack_rows")
+        check(lib.nd_pack_rows(ptr(weight), ptr(self.data), self.N, self.K, self.dtype, _stream(weight)), "nd_pack_rows")
 
 
 def linear(x: torch.Tensor, weight, bias: Optional[torch.Tensor] = None, act=None,
@@ -69,10 +72,10 @@ def linear(x: torch.Tensor, weight, bias: Optional[torch.Tensor] = None, act=Non
     bias = _f32(bias, "bias") if bias is not None else None
     scale = _f32(scale, "scale") if scale is not None else None
     out = torch.empty(M, N, dtype=torch.float32, device=x.device)
-    nbytes = lib.nd_linear_workspace_bytes(M, K, N)
+    nbytes = lib.nd_linear_workspace_bytes(M, K, N, weight.dtype)
     ws = _workspace(nbytes, x.device)
-    check(lib.nd_linear(ptr(x), ptr(wdata), ptr(scale), ptr(bias), ptr(out), M, K, N, ACT[act], ptr(ws), ws.numel(),
-                        _stream(x)), "nd_linear")
+    check(lib.nd_linear(ptr(x), ptr(wdata), ptr(scale), ptr(bias), ptr(out), M, K, N, ACT[act], weight.dtype, ptr(ws),
+                        ws.numel(), _stream(x)), "nd_linear")
     return out
 
 

@@ -50,6 +50,9 @@ class Diffusion(object):
         weights; otherwise they are read from the reference's checkpoint layout."""
         self.args, self.config = args, config
         self.seed = getattr(args, "seed", 0)
+        # operand dtype of the weight-streaming layers: --fp16 (or model.operand_dtype: f16 in the YAML) selects the fp16
+        # mode of BASELINE config 5; the reference itself only has fp32
+        self.operand_dtype = "f16" if getattr(args, "fp16", False) else getattr(config.model, "operand_dtype", "f32")
         if device is None:
             device = torch.device("cuda")
         self.device = torch.device(device)
@@ -72,7 +75,7 @@ class Diffusion(object):
             if config.diffusion.aux_cls.arch != "sevit":
                 raise NotImplementedError("only aux_cls.arch == 'sevit' is on the hot path")
             ds = "ChestXRay" if config.data.dataset in CHEST else "ISICSkinCancer"
-            conditioner = load_conditioner(config.diffusion.trained_aux_cls_ckpt_path, ds, self.device)
+            conditioner = load_conditioner(config.diffusion.trained_aux_cls_ckpt_path, ds, self.device, dtype=self.operand_dtype)
         self.cond_pred_model = conditioner
         self.num_noise_estimators_required = len(conditioner.mlps) + 1      # :274 (the +1 is never sampled, Q1)
         self._states = noise_estimator_states
@@ -121,7 +124,7 @@ class Diffusion(object):
         K = len(self.members)
         self.engine = EnsembleEngine(cfg.data.num_classes, cfg.model.data_dim, cfg.model.hidden_dim, cfg.model.feature_dim,
                                      self.num_timesteps, n_members=K, max_batch=max_batch, max_rows=max_batch * mc,
-                                     device=self.device)
+                                     device=self.device, dtype=self.operand_dtype)
         for slot, i in enumerate(self.members):
             self.engine.load_member(slot, self._states[i])
         self.engine.set_schedule(self.alphas, self.one_minus_alphas_bar_sqrt)

@@ -18,6 +18,7 @@ All ``file:line`` citations are relative to /root/reference/.
 """
 from __future__ import annotations
 
+import contextlib
 import math
 from typing import Dict, List, Optional, Sequence
 
@@ -70,6 +71,31 @@ def schedule_tables(schedule: str, num_timesteps: int, start: float, end: float)
 
 
 # ----------------------------------------------------------------------------
+# fp16-operand mode (BASELINE config 5).  NOT a mode of the reference, which is fp32 only: this models what the
+# build's fp16 mode computes so that mode has a checker too -- both operands of the large Linear layers
+# (encoder_x.{0,3,6}, lin2, lin3, the mapping MLP) rounded to fp16 (round to nearest even), exact products, fp32
+# accumulation; everything else (BatchNorm, gains, softplus, lin1, lin4, the sampler state) stays fp32.
+# ----------------------------------------------------------------------------
+_FP16_OPERANDS = False
+
+
+@contextlib.contextmanager
+def fp16_operands(enable: bool = True):
+    global _FP16_OPERANDS
+    prev, _FP16_OPERANDS = _FP16_OPERANDS, bool(enable)
+    try:
+        yield
+    finally:
+        _FP16_OPERANDS = prev
+
+
+def _big_linear(x: Tensor, w: Tensor, b: Optional[Tensor]) -> Tensor:
+    if _FP16_OPERANDS:
+        x, w = x.half().float(), w.half().float()
+    return F.linear(x, w, b)
+
+
+# ----------------------------------------------------------------------------
 # eps_theta network  (diffusion/latent_model.py:93-184, arch == 'linear')
 # ----------------------------------------------------------------------------
 def _bn_eval(u: Tensor, p: Dict[str, Tensor], prefix: str) -> Tensor:
@@ -81,17 +107,18 @@ def _bn_eval(u: Tensor, p: Dict[str, Tensor], prefix: str) -> Tensor:
 def encoder_x(p: Dict[str, Tensor], x: Tensor) -> Tensor:
     """``self.norm(self.encoder_x(x))`` -- latent_model.py:127-135,155,170-171.
     t-invariant part of ConditionalModel.forward."""
-    h = F.linear(x, p["encoder_x.0.weight"], p["encoder_x.0.bias"])
+    h = _big_linear(x, p["encoder_x.0.weight"], p["encoder_x.0.bias"])
     h = F.softplus(_bn_eval(h, p, "encoder_x.1"))
-    h = F.linear(h, p["encoder_x.3.weight"], p["encoder_x.3.bias"])
+    h = _big_linear(h, p["encoder_x.3.weight"], p["encoder_x.3.bias"])
     h = F.softplus(_bn_eval(h, p, "encoder_x.4"))
-    h = F.linear(h, p["encoder_x.6.weight"], p["encoder_x.6.bias"])
+    h = _big_linear(h, p["encoder_x.6.weight"], p["encoder_x.6.bias"])
     return _bn_eval(h, p, "norm")
 
 
 def _cond_linear(p: Dict[str, Tensor], name: str, h: Tensor, t: Tensor) -> Tensor:
     """ConditionalLinear.forward -- latent_model.py:101-105."""
-    out = F.linear(h, p[name + ".lin.weight"], p[name + ".lin.bias"])
+    lin = F.linear if name == "lin1" else _big_linear          # lin1 (2C -> F) is tiny and stays fp32 in every mode
+    out = lin(h, p[name + ".lin.weight"], p[name + ".lin.bias"])
     gamma = F.embedding(t, p[name + ".embed.weight"])
     return gamma.view(-1, out.shape[-1]) * out
 
@@ -226,10 +253,10 @@ def classifier_forward(p: Dict[str, Tensor], x: Tensor) -> Tensor:
     The reference hard-codes reshape(-1, 196*768); small-dim tests use linear1's
     in_features instead, identical at config dims."""
     x = x.reshape(-1, p["linear1.weight"].shape[1])
-    x = F.relu(F.linear(x, p["linear1.weight"], p["linear1.bias"]))
-    x = F.relu(F.linear(x, p["linear2.weight"], p["linear2.bias"]))
-    x = F.relu(F.linear(x, p["linear3.weight"], p["linear3.bias"]))
-    return F.linear(x, p["linear4.weight"], p["linear4.bias"])
+    x = F.relu(_big_linear(x, p["linear1.weight"], p["linear1.bias"]))
+    x = F.relu(_big_linear(x, p["linear2.weight"], p["linear2.bias"]))
+    x = F.relu(_big_linear(x, p["linear3.weight"], p["linear3.bias"]))
+    return _big_linear(x, p["linear4.weight"], p["linear4.bias"])
 
 
 def init_classifier_params(in_features: int, widths: Sequence[int] = (4096, 2048, 128),

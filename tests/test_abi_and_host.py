@@ -52,9 +52,12 @@ def test_abi_argument_validation_without_gpu():
     assert lib.nd_create(ctypes.byref(good), ctypes.byref(h)) == 0
     assert lib.nd_encode(h, 0, 1, None, 4, None) != 0              # workspace not bound
     assert lib.nd_destroy(h) == 0
-    assert lib.nd_linear(None, None, None, None, None, 1, 16, 1, 0, None, 0, None) != 0
-    assert lib.nd_packed_bytes(3, 32) == 16 * 32 * 4               # rows padded to 16
-    assert lib.nd_packed_bytes(3, 30) == 0
+    assert lib.nd_linear(None, None, None, None, None, 1, 16, 1, 0, 0, None, 0, None) != 0
+    assert lib.nd_packed_bytes(3, 32, 0) == 16 * 32 * 4            # rows padded to 16
+    assert lib.nd_packed_bytes(3, 30, 0) == 0
+    assert lib.nd_packed_bytes(3, 64, 1) == 16 * 64 * 2            # fp16 image
+    assert lib.nd_packed_bytes(3, 48, 1) == 0                      # fp16 needs K % 32 == 0
+    assert lib.nd_packed_bytes(3, 32, 7) == 0                      # unknown dtype
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

@@ -1,0 +1,101 @@
+"""fp16-operand mode (BASELINE config 5) through the C ABI.
+
+The reference has no fp16 path, so this mode has no reference-generated fixtures: PARITY UNPINNED.  It is checked
+(a) against the CPU oracle's fp16-operand mode (operands rounded to fp16, exact products, fp32 accumulation) and
+(b) against the fp32 HIP path, which IS pinned to the reference.  Tolerances are stated per check."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import ref_cpu
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(got, ref, tol):
+    got, ref = got.detach().cpu().double(), ref.detach().cpu().double()
+    err = (got - ref).abs().max().item()
+    assert err <= tol * max(1.0, ref.abs().max().item()), err
+
+
+@pytest.mark.parametrize("M,K,N,act", [(1, 64, 16, None), (5, 32, 7, "gelu"), (32, 4096, 4096, "softplus"), (17, 160, 100, "relu"),
+                                       (70, 256, 48, None), (4, 16384, 64, "relu"), (32, 150528, 256, "relu"), (33, 20000 - 32, 130, None)])
+def test_linear_fp16_operands(M, K, N, act):
+    """nd_linear with dtype f16 == F.linear on fp16-rounded operands (products exact in fp32, fp32 accumulation):
+    only the summation order differs -> 2e-5 relative, as for the fp32 kernel."""
+    from nested_diffusion_amd import ops
+    g = torch.Generator().manual_seed(M * 1000 + N)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    s = torch.rand(N, generator=g) + 0.5
+    pw = ops.PackedWeight(w.cuda(), dtype="f16")
+    assert pw.data.numel() * 4 == ((N + 15) // 16) * 16 * K * 2          # half the bytes of the fp32 image
+    out = ops.linear(x.cuda(), pw, b.cuda(), act=act, scale=s.cuda())
+    ref = s * (x.half().double() @ w.half().double().T).float() + b
+    ref = {None: lambda v: v, "softplus": F.softplus, "relu": F.relu, "gelu": F.gelu}[act](ref)
+    _close(out, ref, 2e-5)
+    # and it is a different (coarser) result than the fp32 path: the mode is really on
+    full = s * (x.double() @ w.double().T).float() + b
+    full = {None: lambda v: v, "softplus": F.softplus, "relu": F.relu, "gelu": F.gelu}[act](full)
+    if K >= 4096:
+        assert (out.cpu() - full).abs().max().item() > 1e-6
+
+
+def test_fp16_rejects_k_not_multiple_of_32():
+    from nested_diffusion_amd import _lib, ops
+    with pytest.raises(_lib.NdError):
+        ops.PackedWeight(torch.zeros(4, 48).cuda(), dtype="f16")
+    from nested_diffusion_amd.engine import EnsembleEngine
+    with pytest.raises(_lib.NdError):
+        EnsembleEngine(2, 48, 64, 64, 10, dtype="f16")                      # data_dim % 32 != 0
+
+
+def _member(D, H, Fd, C, T, seed):
+    return ref_cpu.init_cond_model_params(D, H, Fd, C, T, seed=seed)
+
+
+@pytest.mark.parametrize("D,H,Fd,C,T,B,mc", [(64, 64, 64, 2, 10, 3, 1), (96, 128, 160, 3, 12, 5, 2), (32, 32, 32, 2, 6, 33, 1)])
+def test_sampler_fp16_vs_oracle_fp16_mode(D, H, Fd, C, T, B, mc):
+    """encoder, eps_theta and the whole p_sample_loop in fp16-operand mode against the oracle's fp16-operand mode.
+    Activations are rounded to fp16 after an fp32 epilogue whose operation order differs from the oracle's (folded
+    BatchNorm), so an element can land on the neighbouring fp16 value: tolerance 2e-3 relative on xe / eps,
+    5e-3 absolute on y_0 (fp32 path: 5e-5)."""
+    from nested_diffusion_amd.engine import EnsembleEngine
+    p = _member(D, H, Fd, C, T, seed=11 + D)
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(B, D, generator=g)
+    yhat = torch.softmax(torch.randn(B, C, generator=g), -1)
+    alphas, omabs = ref_cpu.schedule_tables("linear", T, 1e-4, 0.02)
+    eng = EnsembleEngine(C, D, H, Fd, T, n_members=1, max_batch=B, max_rows=B * mc, dtype="f16")
+    eng.load_member(0, p)
+    eng.set_schedule(alphas, omabs)
+    eng.encode(x)
+    with ref_cpu.fp16_operands():
+        xe_ref = ref_cpu.encoder_x(p, x)
+    xe = eng.member_buffer(0, 0, B).cpu()
+    _close(xe, xe_ref, 2e-3)
+    y = torch.randn(B, C, generator=g)
+    for t in (0, T // 2, T - 1):
+        with ref_cpu.fp16_operands():
+            eps_ref = ref_cpu.trunk(p, xe_ref, y, torch.tensor([t]), yhat)
+        _close(eng.eps_theta(0, y, yhat, t).cpu(), eps_ref, 2e-3)
+    noise = torch.randn(T, B * mc, C, generator=g)
+    y0 = eng.sample(yhat[None], yhat[None], noise[None], mc=mc, T=T)[0].cpu()
+    with ref_cpu.fp16_operands():
+        ref = ref_cpu.p_sample_loop(p, x.repeat(mc, 1), yhat.repeat(mc, 1), yhat.repeat(mc, 1), T, alphas, omabs, noise, True)
+    assert (y0 - ref).abs().max().item() < 5e-3
+    # the fp16 mode stays close to the reference's fp32 arithmetic
+    ref32 = ref_cpu.p_sample_loop(p, x.repeat(mc, 1), yhat.repeat(mc, 1), yhat.repeat(mc, 1), T, alphas, omabs, noise, True)
+    assert (y0 - ref32).abs().max().item() < 2e-2
+
+
+def test_classifier_fp16_vs_oracle_fp16_mode():
+    from nested_diffusion_amd.mapping import Classifier
+    p = ref_cpu.init_classifier_params(64 * 6, widths=(96, 64, 32), num_classes=2, seed=3)
+    x = torch.randn(5, 6, 64, generator=torch.Generator().manual_seed(1))
+    out = Classifier(p, "cuda", dtype="f16")(x.cuda()).cpu()
+    with ref_cpu.fp16_operands():
+        ref = ref_cpu.classifier_forward(p, x)
+    _close(out, ref, 2e-3)

@@ -1,5 +1,5 @@
 """Sampler-only timing (K members x T steps in one hipGraph) with the in-graph kernel probes.  GPU only.
-   python tools/bench_sampler.py [K T B mc]      env knobs of the library (e.g. ND_RESIDENT) apply."""
+   [ND_DTYPE=f16] python tools/bench_sampler.py [K T B mc]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -11,7 +11,8 @@ K, T, B, mc = (int(v) for v in (sys.argv[1:5] + ["5", "100", "32", "1"][len(sys.
 D, H, F, C = 1024, 4096, 4096, 2     # the step loop never touches data_dim: a small encoder keeps set-up short
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
-eng = EnsembleEngine(C, D, H, F, T, n_members=K, max_batch=B, max_rows=B * mc, device=dev)
+DT = os.environ.get("ND_DTYPE", "f32")
+eng = EnsembleEngine(C, D, H, F, T, n_members=K, max_batch=B, max_rows=B * mc, device=dev, dtype=DT)
 for k in range(K):
     eng.load_member(k, synthetic.cond_model_state(D, H, F, C, T, seed=1000 + k, device=dev))
 betas = make_beta_schedule("linear", T, 1e-4, 0.02).to(dev)
@@ -32,5 +33,5 @@ for _ in range(reps):
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / reps
 head, l2, l3, n = eng.profile_read()
-print(f"ND_RESIDENT={os.environ.get('ND_RESIDENT','-')} K={K} T={T} B={B} mc={mc}: sampler {ms:.3f} ms = {ms*1e3/T:.1f} us/step; "
+print(f"dtype={DT} K={K} T={T} B={B} mc={mc}: sampler {ms:.3f} ms = {ms*1e3/T:.1f} us/step; "
       f"head {head:.1f} lin2 {l2:.1f} lin3 {l3:.1f} us ({n} probes); checksum {float(y.double().sum()):.9f}")
