@@ -14,6 +14,7 @@
 // kernel's epilogue.  Measured on MI355X (tools/ubench_skinny.hip, 5 members x 67 MB): row-major
 // operands 2.5 TB/s, packed 3.9 TB/s, packed + nontemporal W loads 4.2 TB/s (plain read: 5.4-6.0).
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -127,14 +128,19 @@ __device__ __forceinline__ f16x8 nd_as_h8(const float4& v) {   // the 16 bytes o
     return __builtin_bit_cast(f16x8, v);
 }
 
+// 16-byte load from GLOBAL memory (address space 1: a pointer read out of a descriptor table is generic to the compiler
+// and would become flat_load, which also counts on lgkmcnt).  NT = nontemporal (streamed once).
+typedef __attribute__((address_space(1))) const f32x4 nd_gf4;
 template <bool NT>
 __device__ __forceinline__ float4 nd_ld16(const float* p) {
-    if (NT) {
-        const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
-        return make_float4(v[0], v[1], v[2], v[3]);
-    }
-    return *reinterpret_cast<const float4*>(p);
+    const nd_gf4* g = (const nd_gf4*)p;
+    const f32x4 v = NT ? __builtin_nontemporal_load(g) : *g;
+    return make_float4(v[0], v[1], v[2], v[3]);
 }
+
+#ifdef ND_WG_TIMING
+__device__ long long* nd_dbg_times = nullptr;   // tools/ubench_skinny.hip: per-workgroup (start, loop end, end) clocks
+#endif
 
 // One skinny Linear on packed operands, for `nm` members that share the layer shape (K, N):
 //   MODE 0: out[m,n] = act(scale[t,n] * sum_k x[m,k] w[n,k] + shift[t,n])
@@ -152,16 +158,14 @@ struct SkinnyDesc {
     int K, N, C, act, out_packed;
 };
 
-// WORK DECOMPOSITION.  The nm*ceil(N/16) 16-column output fragments of a launch are numbered
-// member-major and dealt contiguously, NF per workgroup (grid.x); grid.y = 16*MT-row groups; grid.z =
-// k-slabs (MODE 2 only).  A wave keeps NF weight fragments and MT activation fragments per 16-float
-// k-chunk in registers, so an activation fragment is loaded once per NF weight fragments: bytes pulled
-// through L1 per weight byte = 1 + MT/NF.  That ratio, not HBM, is what bounds the NF=1 form (measured:
-// W-only 53 us, W + x from L2 85 us, MFMA-only 50 us, for 5 x 67 MB at M = 32); with NF chosen so that the
-// grid is one workgroup per CU (NF = fragments / 256) the kernel streams at 4.8-4.9 TB/s.
-// The WAVES waves of a workgroup split K (interleaved groups of U chunks) and are summed through LDS in
-// a fixed order => bitwise reproducible.  A workgroup whose fragment range crosses a member boundary
-// takes a single-buffered path that loads the x of its first and of its last member.
+// WORK DECOMPOSITION.  A workgroup never mixes members (it would have to stream two activation matrices and finishes
+// 40 % late: measured).  Each member's nfr = ceil(N/16) 16-column output fragments go to wpm = gridDim.x / nm workgroups:
+// base = nfr / wpm each, the first nfr % wpm of them one more.  NF (template) = the larger count; a workgroup holding
+// NF - 1 fragments skips the last register slot (uniform branch).  The launcher picks wpm so that the grid is at most one
+// workgroup per CU.  grid.y = 16*MT-row groups; grid.z = k-slabs (MODE 2 only).
+// A wave keeps NF weight fragments and MT activation fragments per k-chunk in registers, so an activation fragment is
+// loaded once per NF weight fragments.  The WAVES waves of a workgroup split K (interleaved groups of U chunks) and are
+// summed through LDS in a fixed order => bitwise reproducible.
 // MFMA 16x16x4 f32: A[i=l&15][k=l>>4] <- W rows, B[k=l>>4][j=l&15] <- x rows, D[i=4*(l>>4)+r][j=l&15];
 // lane l's float4 holds k = 4*(l>>4)..+3 of a chunk and element jj feeds MFMA jj (same k permutation on
 // both operands).
@@ -169,67 +173,54 @@ struct SkinnyDesc {
 template <int MT, int NF, int WAVES, int U, int MODE, bool NT, int H = 0>
 __global__ __launch_bounds__(WAVES * 64) void k_skinny(SkinnyDesc d0, const SkinnyDesc* __restrict__ table, int nm,
                                                        int M, int t, int cps) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+#ifdef ND_WG_TIMING
+    const long long dbg_t0 = wall_clock64();
+#endif
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: keeps stream addresses in SGPRs
     const int K = table ? table[0].K : d0.K, N = table ? table[0].N : d0.N;
-    const int nch = H ? K >> 5 : K >> 4, nfr = (N + 15) >> 4, total = nm * nfr, mtiles = (M + 15) >> 4;
-    const int f0 = blockIdx.x * NF;
+    const int nch = H ? K >> 5 : K >> 4, nfr = (N + 15) >> 4, mtiles = (M + 15) >> 4;
+    const int wpm = gridDim.x / nm;                               // workgroups per member
+    const int g = blockIdx.x / wpm, j = blockIdx.x - g * wpm;     // member, workgroup inside the member
+    const int base = nfr / wpm, rem = nfr - base * wpm;
+    const int nact = base + (j < rem ? 1 : 0);                    // fragments this workgroup owns: NF or NF - 1
+    const int fi0 = j * base + min(j, rem);                       // its first fragment inside the member
+    const SkinnyDesc d = table ? table[g] : d0;
     const int c0 = MODE == 2 ? blockIdx.z * cps : 0;
     const int c1 = MODE == 2 ? min(c0 + cps, nch) : nch;
-    int gidx[NF];
     const float* wp[NF];
 #pragma unroll
-    for (int f = 0; f < NF; ++f) {
-        const int fr = min(f0 + f, total - 1);
-        gidx[f] = fr / nfr;
-        const float* wb = table ? table[gidx[f]].w : d0.w;
-        wp[f] = wb + ((size_t)(fr - gidx[f] * nfr) * nch + c0) * 256 + lane * 4;
-    }
-    const int gA = gidx[0], gB = gidx[NF - 1];
-    const float *xA[MT], *xB[MT];
-    {
-        const float* xa = table ? table[gA].x : d0.x;
-        const float* xb = table ? table[gB].x : d0.x;
+    for (int f = 0; f < NF; ++f) wp[f] = d.w + ((size_t)min(fi0 + f, nfr - 1) * nch + c0) * 256;   // uniform; lane term added at the load
+    const float* xp[MT];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const size_t off = ((size_t)min((int)blockIdx.y * MT + mt, mtiles - 1) * nch + c0) * 256 + lane * 4;
-            xA[mt] = xa + off;
-            xB[mt] = xb + off;
-        }
-    }
+    for (int mt = 0; mt < MT; ++mt) xp[mt] = d.x + ((size_t)min((int)blockIdx.y * MT + mt, mtiles - 1) * nch + c0) * 256;
     f32x4 acc[NF][MT];
 #pragma unroll
     for (int f = 0; f < NF; ++f)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[f][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // Epilogue operands are fetched NOW (their latency hides under the weight stream): each thread's
-    // scale/shift entries for the output elements it will finish, and the lin4 rows of MODE 1 into LDS.
+    // Epilogue operands are requested NOW (registers; parked in LDS after the main loop): the scale/shift entries of the
+    // workgroup's output columns and the lin4 rows of MODE 1.
     constexpr int EPT = (MT * 256 + WAVES * 64 - 1) / (WAVES * 64);   // epilogue elements per thread
-    float esc[NF][EPT], esh[NF][EPT];
-    int eact = 0, eC = 0, epacked = 0;
+    __shared__ float ssc[NF][16], ssh[NF][16];
     __shared__ float pws[MODE == 1 ? NF : 1][MODE == 1 ? 8 : 1][16];
+    const int eact = d.act, eC = d.C, epacked = d.out_packed;
+    float r_sc = 1.0f, r_sh = 0.0f, r_pw = 0.0f;
     if (MODE != 2) {
-        eact = table ? table[0].act : d0.act;
-        eC = table ? table[0].C : d0.C;
-        epacked = table ? table[0].out_packed : d0.out_packed;
-#pragma unroll
-        for (int f = 0; f < NF; ++f) {
-            const int fr = min(f0 + f, total - 1), g = gidx[f], n0 = (fr - g * nfr) * 16;
-            const float* scp = table ? table[g].scale : d0.scale;
-            const float* shp = table ? table[g].shift : d0.shift;
-#pragma unroll
-            for (int q = 0; q < EPT; ++q) {
-                const int e = tid + q * WAVES * 64, l = e & 63, r = (e >> 6) & 3;
-                const int n = min(n0 + 4 * (l >> 4) + r, N - 1);
-                esc[f][q] = scp ? scp[(size_t)t * N + n] : 1.0f;
-                esh[f][q] = shp ? shp[(size_t)t * N + n] : 0.0f;
-            }
-            if (MODE == 1) {
-                const float* pwp = table ? table[g].pw : d0.pw;
-                if (tid < eC * 16) {
-                    const int c = tid >> 4, nl = tid & 15;
-                    pws[f][c][nl] = (n0 + nl < N) ? pwp[(size_t)c * N + n0 + nl] : 0.f;
-                }
+        // thread tid < NF*16 owns column (f = tid/16, nl = tid%16); thread tid < NF*C*16 owns lin4 entry (f, c, nl)
+        if (tid < NF * 16) {
+            const int n = min(min(fi0 + (tid >> 4), nfr - 1) * 16 + (tid & 15), N - 1);
+            if (d.scale) r_sc = d.scale[(size_t)t * N + n];
+            if (d.shift) r_sh = d.shift[(size_t)t * N + n];
+        }
+        if (MODE == 1) {
+            const bool one_pass = NF * eC * 16 <= WAVES * 64;          // one entry per thread: keep it in a register for now
+            for (int e = tid; e < NF * eC * 16; e += WAVES * 64) {
+                const int f = e / (eC * 16), c = (e / 16) % eC, nl = e & 15;
+                const int n = min(fi0 + f, nfr - 1) * 16 + nl;
+                r_pw = n < N ? d.pw[(size_t)c * N + n] : 0.f;
+                if (!one_pass) pws[f][c][nl] = r_pw;                    // more entries than threads (large C): store at once
             }
         }
     }
@@ -239,211 +230,189 @@ __global__ __launch_bounds__(WAVES * 64) void k_skinny(SkinnyDesc d0, const Skin
     const int ngw = ngroups > wave ? (ngroups - wave + WAVES - 1) / WAVES : 0;
     const int glast = ngroups > 0 ? ngroups - 1 : 0;
 
-    float4 wc[U][NF], xc[U][MT];
-    auto LDW = [&](float4 (&w)[U][NF], int grp) {
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-            for (int f = 0; f < NF; ++f) w[u][f] = nd_ld16<NT>(wp[f] + ((size_t)grp * U + u) * 256);
-    };
-    auto LDX = [&](float4 (&x)[U][MT], const float* const (&xb)[MT], int grp) {
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) x[u][mt] = nd_ld16<false>(xb[mt] + ((size_t)grp * U + u) * 256);
-    };
-    if (gA == gB) {
-        float4 wn[U][NF], xn[U][MT];
-        if (ngw > 0) { LDW(wc, min(wave, glast)); LDX(xc, xA, min(wave, glast)); }
-        for (int i = 0; i < ngw; ++i) {
-            // prefetch the next group (clamped: the last iteration re-reads a valid group, unused)
-            const int gn = min(wave + (i + 1) * WAVES, glast);
-            LDW(wn, gn); LDX(xn, xA, gn);
-            if (H) {
-#pragma unroll
-                for (int u = 0; u < U; ++u)
-#pragma unroll
-                    for (int f = 0; f < NF; ++f)
-#pragma unroll
-                        for (int mt = 0; mt < MT; ++mt)
-                            acc[f][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(nd_as_h8(wc[u][f]), nd_as_h8(xc[u][mt]), acc[f][mt], 0, 0, 0);
-            } else {
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int f = 0; f < NF; ++f) {
-                        const float wv = j == 0 ? wc[u][f].x : j == 1 ? wc[u][f].y : j == 2 ? wc[u][f].z : wc[u][f].w;
-#pragma unroll
-                        for (int mt = 0; mt < MT; ++mt) {
-                            const float xv = j == 0 ? xc[u][mt].x : j == 1 ? xc[u][mt].y : j == 2 ? xc[u][mt].z : xc[u][mt].w;
-                            acc[f][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, xv, acc[f][mt], 0, 0, 0);
-                        }
-                    }
-            }
+    // MAIN LOOP.  Two register stages (A, B), each a whole group of U chunks (NF weight + MT activation fragments), used
+    // alternately with no copies: the loads of the next group are issued, THEN the MFMAs of the current one run, so every
+    // wave keeps one group in flight under its arithmetic.  The scheduling barriers pin that order (left alone, the
+    // compiler sinks the loads below the MFMAs to save registers and then waits on them at once).
+    // FULL = false (a workgroup with NF - 1 fragments): the last fragment slot is neither loaded nor multiplied.
+    const int lane4 = lane * 4;
+    auto run = [&](auto ntc, auto fullc) {
+        constexpr bool NTV = decltype(ntc)::value, FULL = decltype(fullc)::value;
+        constexpr int NFA = FULL ? NF : (NF > 1 ? NF - 1 : 1);         // active fragment slots
+        float4 wA[U][NFA], xA[U][MT], wB[U][NFA], xB[U][MT];
+        auto LD = [&](float4 (&w)[U][NFA], float4 (&x)[U][MT], int grp) {
+            const size_t go = (size_t)grp * U * 256;
 #pragma unroll
             for (int u = 0; u < U; ++u) {
 #pragma unroll
-                for (int f = 0; f < NF; ++f) wc[u][f] = wn[u][f];
+                for (int f = 0; f < NFA; ++f) w[u][f] = nd_ld16<NTV>(wp[f] + go + u * 256 + lane4);
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) xc[u][mt] = xn[u][mt];
+                for (int mt = 0; mt < MT; ++mt) x[u][mt] = nd_ld16<false>(xp[mt] + go + u * 256 + lane4);
             }
-        }
-    } else {
-        float4 xb[U][MT];
-        for (int i = 0; i < ngw; ++i) {
-            const int gn = wave + i * WAVES;
-            LDW(wc, gn); LDX(xc, xA, gn); LDX(xb, xB, gn);
-            if (H) {
-#pragma unroll
-                for (int u = 0; u < U; ++u)
-#pragma unroll
-                    for (int f = 0; f < NF; ++f) {
-                        const bool useB = gidx[f] != gA;
-#pragma unroll
-                        for (int mt = 0; mt < MT; ++mt)
-                            acc[f][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(nd_as_h8(wc[u][f]), nd_as_h8(useB ? xb[u][mt] : xc[u][mt]),
-                                                                                acc[f][mt], 0, 0, 0);
-                    }
-            } else {
+        };
+        auto MMA = [&](const float4 (&w)[U][NFA], const float4 (&x)[U][MT]) {
 #pragma unroll
             for (int u = 0; u < U; ++u)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int jj = 0; jj < (H ? 1 : 4); ++jj)
 #pragma unroll
-                    for (int f = 0; f < NF; ++f) {
-                        const float wv = j == 0 ? wc[u][f].x : j == 1 ? wc[u][f].y : j == 2 ? wc[u][f].z : wc[u][f].w;
-                        const bool useB = gidx[f] != gA;
+                    for (int f = 0; f < NFA; ++f)
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt) {
-                            const float xa = j == 0 ? xc[u][mt].x : j == 1 ? xc[u][mt].y : j == 2 ? xc[u][mt].z : xc[u][mt].w;
-                            const float xv = j == 0 ? xb[u][mt].x : j == 1 ? xb[u][mt].y : j == 2 ? xb[u][mt].z : xb[u][mt].w;
-                            acc[f][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, useB ? xv : xa, acc[f][mt], 0, 0, 0);
+                            if (H) {
+                                acc[f][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(nd_as_h8(w[u][f]), nd_as_h8(x[u][mt]), acc[f][mt], 0, 0, 0);
+                            } else {
+                                const float wv = jj == 0 ? w[u][f].x : jj == 1 ? w[u][f].y : jj == 2 ? w[u][f].z : w[u][f].w;
+                                const float xv = jj == 0 ? x[u][mt].x : jj == 1 ? x[u][mt].y : jj == 2 ? x[u][mt].z : x[u][mt].w;
+                                acc[f][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, xv, acc[f][mt], 0, 0, 0);
+                            }
                         }
-                    }
-            }
+        };
+        auto G = [&](int i) { return min(wave + i * WAVES, glast); };      // group of this wave's i-th turn (clamped)
+        int i = 0;
+        if (ngw > 0) LD(wA, xA, G(0));
+        for (; i + 1 < ngw; i += 2) {
+            LD(wB, xB, G(i + 1));
+            __builtin_amdgcn_sched_barrier(0);
+            MMA(wA, xA);
+            __builtin_amdgcn_sched_barrier(0);
+            LD(wA, xA, G(i + 2));          // i + 2 == ngw on the last pair of an even count: re-reads a valid group, unused
+            __builtin_amdgcn_sched_barrier(0);
+            MMA(wB, xB);
+            __builtin_amdgcn_sched_barrier(0);
         }
+        if (i < ngw) MMA(wA, xA);
+    };
+    if (nact == NF) {
+        if (NT) run(std::true_type{}, std::true_type{});
+        else run(std::false_type{}, std::true_type{});
+    } else {
+        if (NT) run(std::true_type{}, std::false_type{});
+        else run(std::false_type{}, std::false_type{});
     }
     // leftover chunks (chunk count not a multiple of U): chunk c goes to wave c % WAVES
     for (int c = ngroups * U + wave; c < nck; c += WAVES) {
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
-            const float4 w4 = *reinterpret_cast<const float4*>(wp[f] + (size_t)c * 256);
+            const float4 w4 = nd_ld16<false>(wp[f] + (size_t)c * 256 + lane4);
             const float wv[4] = {w4.x, w4.y, w4.z, w4.w};
-            const bool useB = gidx[f] != gA;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                const float4 x4 = *reinterpret_cast<const float4*>((useB ? xB[mt] : xA[mt]) + (size_t)c * 256);
+                const float4 x4 = nd_ld16<false>(xp[mt] + (size_t)c * 256 + lane4);
                 const float xv[4] = {x4.x, x4.y, x4.z, x4.w};
                 if (H) acc[f][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(nd_as_h8(w4), nd_as_h8(x4), acc[f][mt], 0, 0, 0);
                 else {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[f][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[j], xv[j], acc[f][mt], 0, 0, 0);
+                    for (int jj = 0; jj < 4; ++jj) acc[f][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[jj], xv[jj], acc[f][mt], 0, 0, 0);
                 }
             }
         }
     }
+#ifdef ND_WG_TIMING
+    const long long dbg_t1 = wall_clock64();
+#endif
+    // park the epilogue operands (in registers since the prologue) in LDS; the first barrier below publishes them
+    if (MODE != 2) {
+        if (tid < NF * 16) { ssc[tid >> 4][tid & 15] = r_sc; ssh[tid >> 4][tid & 15] = r_sh; }
+        if (MODE == 1 && NF * eC * 16 <= WAVES * 64 && tid < NF * eC * 16) pws[tid / (eC * 16)][(tid / 16) % eC][tid & 15] = r_pw;
+    }
 
-    // ---- per fragment: cross-wave reduction (fixed order) + epilogue ----
-    __shared__ float red[WAVES][MT][4][64];
-    __shared__ __attribute__((aligned(16))) float tile[16 * MT][20];
+    // ---- all fragments at once: cross-wave reduction (fixed order) + epilogue, two barriers in total ----
+    // red[w] holds wave w's accumulators in MFMA D order, element ((f*MT + mt)*4 + r)*64 + l  <->  n = 4*(l>>4)+r, m = l&15.
+    // The reduced, activated value replaces plane 0 in place (same thread reads the four planes and writes plane 0).
+    __shared__ __attribute__((aligned(16))) float red[WAVES][NF * MT * 256];
 #pragma unroll
-    for (int f = 0; f < NF; ++f) {
-        const int fr = f0 + f;
-        if (fr < total) {                           // uniform across the workgroup
-            if (f > 0) __syncthreads();
+    for (int f = 0; f < NF; ++f)
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) red[wave][mt][r][lane] = acc[f][mt][r];
-            __syncthreads();
-            const int g = gidx[f], nfi = fr - g * nfr, n0 = nfi * 16;
-            if (MODE == 2) {
-                float* partp = table ? table[g].part : d0.part;
-                // raw partial sums, [slab][Mp][Np]; lane l of the reduced tile owns n = 4*(l>>4)+r, m = l&15
-                const int Mp = mtiles * 16, Np = nfr * 16;
-                for (int e = tid; e < MT * 64; e += WAVES * 64) {
-                    const int mt = e >> 6, l = e & 63;
+            for (int r = 0; r < 4; ++r) red[wave][((f * MT + mt) * 4 + r) * 64 + lane] = acc[f][mt][r];
+    __syncthreads();
+    float* const R = red[0];
+    const int m0 = blockIdx.y * 16 * MT;
+    if (MODE == 2) {
+        // raw partial sums, [slab][Mp][Np]; lane l of a reduced tile owns n = 4*(l>>4)..+3 of row m = l&15
+        const int Mp = mtiles * 16, Np = nfr * 16;
+        for (int e = tid; e < nact * MT * 64; e += WAVES * 64) {
+            const int f = e / (MT * 64), mt = (e >> 6) % MT, l = e & 63;
+            const int mtg = blockIdx.y * MT + mt;
+            if (mtg < mtiles) {
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int q = ((f * MT + mt) * 4 + r) * 64 + l;
+                    float sum = red[0][q];
+#pragma unroll
+                    for (int w = 1; w < WAVES; ++w) sum += red[w][q];
+                    v[r] = sum;
+                }
+                *reinterpret_cast<float4*>(d.part + ((size_t)blockIdx.z * Mp + mtg * 16 + (l & 15)) * Np + (fi0 + f) * 16 + 4 * (l >> 4)) =
+                    make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+    } else {
+        for (int q = tid; q < nact * MT * 256; q += WAVES * 64) {
+            const int f = q / (MT * 256), r = (q >> 6) & 3, l = q & 63;
+            float sum = red[0][q];
+#pragma unroll
+            for (int w = 1; w < WAVES; ++w) sum += red[w][q];
+            const int nl = 4 * (l >> 4) + r;
+            R[q] = ((fi0 + f) * 16 + nl < N) ? nd_act(ssc[f][nl] * sum + ssh[f][nl], eact) : 0.f;
+        }
+        __syncthreads();
+        if (MODE == 0) {
+            if (epacked == 2) {
+                // frag32h: a fragment's 16 columns are k-groups (nfi&1)*2 + {0,1} of block (m-tile, nfi/2): lanes
+                // 32*(nfi&1) .. +31 of it, 512 contiguous bytes per m-tile
+                _Float16* outh = reinterpret_cast<_Float16*>(d.out);
+                const int nch_o = N >> 5;
+                for (int e = tid; e < nact * MT * 32; e += WAVES * 64) {
+                    const int f = e / (MT * 32), mt = (e >> 5) % MT, L = e & 31, nfi = fi0 + f;
                     const int mtg = blockIdx.y * MT + mt;
                     if (mtg < mtiles) {
-                        float v[4];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            float s = red[0][mt][r][l];
-#pragma unroll
-                            for (int w = 1; w < WAVES; ++w) s += red[w][mt][r][l];
-                            v[r] = s;
-                        }
-                        *reinterpret_cast<float4*>(partp + ((size_t)blockIdx.z * Mp + mtg * 16 + (l & 15)) * Np + n0 + 4 * (l >> 4)) =
-                            make_float4(v[0], v[1], v[2], v[3]);
+                        const float* tp = R + (f * MT + mt) * 256 + (L & 15) + 32 * (L >> 4);   // l0 = m + 16*(2*(L>>4)), l1 = l0 + 16
+                        const f16x8 h = {(_Float16)tp[0], (_Float16)tp[64], (_Float16)tp[128], (_Float16)tp[192],
+                                         (_Float16)tp[16], (_Float16)tp[80], (_Float16)tp[144], (_Float16)tp[208]};
+                        *reinterpret_cast<f16x8*>(outh + ((size_t)mtg * nch_o + (nfi >> 1)) * 512 + ((nfi & 1) * 32 + L) * 8) = h;
+                    }
+                }
+            } else if (epacked) {
+                // the 16x16 block (m-tile, fragment) is one contiguous 1 KiB of the frag16 output
+                for (int e = tid; e < nact * MT * 64; e += WAVES * 64) {
+                    const int f = e / (MT * 64), mt = (e >> 6) % MT, L = e & 63;
+                    const int mtg = blockIdx.y * MT + mt;
+                    if (mtg < mtiles) {
+                        const float* tp = R + (f * MT + mt) * 256 + L;
+                        *reinterpret_cast<float4*>(d.out + ((size_t)mtg * nfr + fi0 + f) * 256 + L * 4) = make_float4(tp[0], tp[64], tp[128], tp[192]);
                     }
                 }
             } else {
-#pragma unroll
-                for (int q = 0; q < EPT; ++q) {
-                    const int e = tid + q * WAVES * 64;
-                    if (e < MT * 256) {
-                        const int mt = e >> 8, r = (e >> 6) & 3, l = e & 63;
-                        float s = red[0][mt][r][l];
-#pragma unroll
-                        for (int w = 1; w < WAVES; ++w) s += red[w][mt][r][l];
-                        const int nl = 4 * (l >> 4) + r, ml = 16 * mt + (l & 15);
-                        tile[ml][nl] = (n0 + nl < N) ? nd_act(esc[f][q] * s + esh[f][q], eact) : 0.f;
-                    }
+                for (int e = tid; e < nact * MT * 256; e += WAVES * 64) {
+                    const int f = e / (MT * 256), ml = (e >> 4) % (16 * MT), nl = e & 15;
+                    const int m = m0 + ml, n = (fi0 + f) * 16 + nl;
+                    if (m < M && n < N) d.out[(size_t)m * N + n] = R[((f * MT + (ml >> 4)) * 4 + (nl & 3)) * 64 + (ml & 15) + 16 * (nl >> 2)];
                 }
-                __syncthreads();
-                const int m0 = blockIdx.y * 16 * MT;
-                if (MODE == 0) {
-                    float* outp = table ? table[g].out : d0.out;
-                    if (epacked == 2) {
-                        // frag32h: this fragment's 16 columns are k-groups (nfi&1)*2 + {0,1} of block (m-tile, nfi/2): lanes
-                        // 32*(nfi&1) .. +31 of it, 512 contiguous bytes per m-tile
-                        _Float16* outh = reinterpret_cast<_Float16*>(outp);
-                        const int nch_o = N >> 5;
-                        for (int e = tid; e < MT * 32; e += WAVES * 64) {
-                            const int mt = e >> 5, L = e & 31;
-                            const int mtg = blockIdx.y * MT + mt;
-                            if (mtg < mtiles) {
-                                const float* tp = &tile[16 * mt + (L & 15)][8 * (L >> 4)];
-                                const f16x8 h = {(_Float16)tp[0], (_Float16)tp[1], (_Float16)tp[2], (_Float16)tp[3],
-                                                 (_Float16)tp[4], (_Float16)tp[5], (_Float16)tp[6], (_Float16)tp[7]};
-                                *reinterpret_cast<f16x8*>(outh + ((size_t)mtg * nch_o + (nfi >> 1)) * 512 + ((nfi & 1) * 32 + L) * 8) = h;
-                            }
-                        }
-                    } else if (epacked) {
-                        // the 16x16 block (m-tile, this fragment) is one contiguous 1 KiB of the frag16 output
-                        for (int e = tid; e < MT * 64; e += WAVES * 64) {
-                            const int mt = e >> 6, L = e & 63;
-                            const int mtg = blockIdx.y * MT + mt;
-                            if (mtg < mtiles) {
-                                const float4 v = *reinterpret_cast<const float4*>(&tile[16 * mt + (L & 15)][4 * (L >> 4)]);
-                                *reinterpret_cast<float4*>(outp + ((size_t)mtg * nfr + nfi) * 256 + L * 4) = v;
-                            }
-                        }
-                    } else {
-                        for (int e = tid; e < 16 * MT * 16; e += WAVES * 64) {
-                            const int ml = e >> 4, nl = e & 15;
-                            const int m = m0 + ml, n = n0 + nl;
-                            if (m < M && n < N) outp[(size_t)m * N + n] = tile[ml][nl];
-                        }
-                    }
-                } else {
-                    float* partp = table ? table[g].part : d0.part;
-                    for (int e = tid; e < 16 * MT * eC; e += WAVES * 64) {
-                        const int ml = e / eC, c = e - ml * eC;
-                        const int m = m0 + ml;
-                        if (m < M) {
-                            float s = 0.f;
+            }
+        } else {
+            for (int e = tid; e < nact * 16 * MT * eC; e += WAVES * 64) {
+                const int f = e / (16 * MT * eC), ml = (e / eC) % (16 * MT), c = e % eC;
+                const int m = m0 + ml;
+                if (m < M) {
+                    const float* tp = R + (f * MT + (ml >> 4)) * 256 + (ml & 15);
+                    float sum = 0.f;
 #pragma unroll
-                            for (int nl = 0; nl < 16; ++nl) s += pws[MODE == 1 ? f : 0][MODE == 1 ? c : 0][nl] * tile[ml][nl];
-                            partp[((size_t)m * eC + c) * nfr + nfi] = s;
-                        }
-                    }
+                    for (int nl = 0; nl < 16; ++nl) sum += pws[MODE == 1 ? f : 0][MODE == 1 ? c : 0][nl] * tp[(nl & 3) * 64 + 16 * (nl >> 2)];
+                    d.part[((size_t)m * eC + c) * nfr + fi0 + f] = sum;
                 }
             }
         }
     }
+#ifdef ND_WG_TIMING
+    if (tid == 0 && nd_dbg_times) {
+        long long* q = nd_dbg_times + (size_t)blockIdx.x * 3;
+        q[0] = dbg_t0; q[1] = dbg_t1; q[2] = wall_clock64();
+    }
+#endif
 }
 
 // out[m,n] = act(scale[n] * sum_s part[s,m,n] + shift[n]); slabs summed in order (reproducible).
@@ -493,51 +462,58 @@ static inline bool nd_use_splitk(int K) { return K >= 16384; }
 
 struct SkinnyLaunch { void* fn; dim3 grid; dim3 block; int cps; int S; };
 
-// Geometry: NF = fragments per workgroup so that the grid is ~one workgroup per CU (256), at most 5
-// (register budget at MT = 2 with 16 waves); 16 waves for MT <= 2, 8 for MT = 4.  Weights larger than what
-// the 256 MiB Infinity Cache keeps across consecutive steps are streamed with nontemporal loads.
-// MODE 2 (split-K): S k-slabs in grid.z so that (fragment groups) x (row groups) x S >= 1024 workgroups.
+// Geometry.  Measured (tools/ubench_skinny.hip, "sx" study, 5 x 67 MB at M = 32): weight stream alone 51 us, f32 MFMAs alone
+// 40 us; together 80 us with 16 waves per CU, 66 us with 8, 57 us (min 51) with FOUR -- one wave per SIMD, each keeping two
+// register stages so its own loads fly under its own MFMAs.  More waves per SIMD make the two overlap worse, not better.
+// So: 4-wave workgroups, at most one per CU, every member's fragments spread evenly over its share of them (5 or 6 each at
+// K = 5 members: 255 workgroups), U chunks per stage chosen to keep ~8-16 KiB per wave in flight.  Weights larger than what the 256 MiB Infinity Cache keeps
+// across consecutive steps are streamed with nontemporal loads.
+// MODE 2 (split-K): S k-slabs in grid.z so that (fragment groups) x (row groups) x S ~ 256 workgroups.
 template <int MODE>
 static inline SkinnyLaunch nd_skinny_launch(int K, int N, int M, int nm, int half = 0) {
     const int mt = nd_pick_mt(M);
-    const int nfr = (N + 15) / 16, total = nm * nfr, nch = half ? K / 32 : K / 16;
+    const int nfr = (N + 15) / 16, nch = half ? K / 32 : K / 16;
     const int mgroups = (M + 16 * mt - 1) / (16 * mt);
-    const int nfmax = mt == 4 ? 2 : 5;
-    int nf = total / 256;
-    nf = nf < 1 ? 1 : (nf > nfmax ? nfmax : nf);
+    const int nfmax = mt == 4 ? 3 : 6;             // register budget (accumulators + two stages)
+    // workgroups per member: as many as keep the grid within one workgroup per CU, but no workgroup above nfmax fragments
+    int wpm = 256 / nm;
+    if (wpm < 1) wpm = 1;
+    if (wpm > nfr) wpm = nfr;
+    while ((nfr + wpm - 1) / wpm > nfmax) ++wpm;
+    const int nf = (nfr + wpm - 1) / wpm;          // = base + (nfr % wpm != 0): the kernel's fragment slots
+    const int gx = nm * wpm;
     int S = 1, cps = nch;
     if (MODE == 2) {
-        nf = total >= 256 ? 4 : (total >= 128 ? 2 : 1);
-        if (nf > nfmax) nf = nfmax;
-        const int gx = (total + nf - 1) / nf;
-        S = (1024 + gx * mgroups - 1) / (gx * mgroups);   // ~4+ workgroups per CU: even finish without a work queue
+        S = 256 / (gx * mgroups);
         if (S < 1) S = 1;
         while (S > 1 && nch / S < 64) --S;          // keep every slab >= 64 chunks (1024 floats) deep
         cps = (nch + S - 1) / S;
         S = (nch + cps - 1) / cps;
     }
     const bool nt = (double)nm * N * (double)K * (half ? 2.0 : 4.0) > 160e6;
-    SkinnyLaunch L{nullptr, dim3((total + nf - 1) / nf, mgroups, S), dim3(mt == 4 ? 512 : 1024), cps, S};
+    SkinnyLaunch L{nullptr, dim3(gx, mgroups, S), dim3(256), cps, S};
 #define ND_SK(MTV, NFV, WV, UV)                                                                                     \
     (half ? (nt ? (void*)k_skinny<MTV, NFV, WV, UV, MODE, true, 1> : (void*)k_skinny<MTV, NFV, WV, UV, MODE, false, 1>) \
           : (nt ? (void*)k_skinny<MTV, NFV, WV, UV, MODE, true, 0> : (void*)k_skinny<MTV, NFV, WV, UV, MODE, false, 0>))
     if (mt == 4) {
-        L.fn = nf == 1 ? ND_SK(4, 1, 8, 2) : ND_SK(4, 2, 8, 2);
+        L.fn = nf == 1 ? ND_SK(4, 1, 4, 2) : (nf == 2 ? ND_SK(4, 2, 4, 2) : ND_SK(4, 3, 4, 2));
     } else if (mt == 2) {
         switch (nf) {
-            case 1: L.fn = ND_SK(2, 1, 16, 2); break;
-            case 2: L.fn = ND_SK(2, 2, 16, 2); break;
-            case 3: L.fn = ND_SK(2, 3, 16, 2); break;
-            case 4: L.fn = ND_SK(2, 4, 16, 1); break;
-            default: L.fn = ND_SK(2, 5, 16, 1); break;
+            case 1: L.fn = ND_SK(2, 1, 4, 4); break;
+            case 2: L.fn = ND_SK(2, 2, 4, 4); break;
+            case 3: L.fn = ND_SK(2, 3, 4, 2); break;
+            case 4: L.fn = ND_SK(2, 4, 4, 2); break;
+            case 5: L.fn = ND_SK(2, 5, 4, 2); break;
+            default: L.fn = ND_SK(2, 6, 4, 2); break;
         }
     } else {
         switch (nf) {
-            case 1: L.fn = ND_SK(1, 1, 16, 2); break;
-            case 2: L.fn = ND_SK(1, 2, 16, 2); break;
-            case 3: L.fn = ND_SK(1, 3, 16, 2); break;
-            case 4: L.fn = ND_SK(1, 4, 16, 2); break;
-            default: L.fn = ND_SK(1, 5, 16, 2); break;
+            case 1: L.fn = ND_SK(1, 1, 4, 4); break;
+            case 2: L.fn = ND_SK(1, 2, 4, 4); break;
+            case 3: L.fn = ND_SK(1, 3, 4, 2); break;
+            case 4: L.fn = ND_SK(1, 4, 4, 2); break;
+            case 5: L.fn = ND_SK(1, 5, 4, 2); break;
+            default: L.fn = ND_SK(1, 6, 4, 2); break;
         }
     }
 #undef ND_SK

@@ -48,7 +48,7 @@ def test_main_test_path_end_to_end(tmp_path, capsys, monkeypatch):
     ypath, vp, mlps, members, dims = _write_run(str(tmp_path), T=T, K=K, B=B)
     # the tiny ViT of this test has 2 heads of 64 (the real one 12): the loader's default is 12
     orig = mapping.load_conditioner
-    monkeypatch.setattr(mapping, "load_conditioner", lambda path, ds, device="cuda", num_heads=12: orig(path, ds, device, dims["heads"]))
+    monkeypatch.setattr(mapping, "load_conditioner", lambda path, ds, device="cuda", num_heads=12, dtype="f32": orig(path, ds, device, dims["heads"], dtype))
     import nested_diffusion_amd.runner as runner_mod
     monkeypatch.setattr(runner_mod, "load_conditioner", mapping.load_conditioner)
     argv = ["--test", "--device", "0", "--thread", "8", "--loss", "card_onehot_conditional", "--config", ypath,
@@ -95,7 +95,7 @@ def test_calib_path_nelder_mead(tmp_path, capsys, monkeypatch):
     import nested_diffusion_amd.runner as runner_mod
     ypath, vp, mlps, members, dims = _write_run(str(tmp_path), T=5, K=5, B=8)
     orig = mapping.load_conditioner
-    monkeypatch.setattr(runner_mod, "load_conditioner", lambda path, ds, device="cuda", num_heads=12: orig(path, ds, device, dims["heads"]))
+    monkeypatch.setattr(runner_mod, "load_conditioner", lambda path, ds, device="cuda", num_heads=12, dtype="f32": orig(path, ds, device, dims["heads"], dtype))
     argv = ["--calib", "--loss", "card_onehot_conditional", "--config", ypath, "--exp", os.path.join(str(tmp_path), "c"), "--doc", "cal",
             "--ni", "--preprocess", "grayscaled", "--timesteps", "5", "--seed", "3", "--synthetic_batches", "2", "--mc_trials", "2"]
     assert nd_main.main(argv) == 0

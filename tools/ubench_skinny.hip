@@ -4,6 +4,7 @@
 // Each variant computes out[g][m][n] = sum_k x[g][m][k] * w[g][n][k] (checked against variant 0),
 // interleaved rounds in one process, median + min reported as GB/s of weight bytes.
 #include <hip/hip_runtime.h>
+#define ND_WG_TIMING
 #include "../nested_diffusion_amd/csrc/nd_common.hpp"
 #include <algorithm>
 #include <cstdio>
@@ -146,6 +147,171 @@ __global__ __launch_bounds__(256) void k_stream(const float* w, size_t n4, float
     }
     for (; i < n4; i += stride) s += p[i].x;
     if (s == 123.456f) out[0] = s;
+}
+
+// Streaming-shape study: W-only reads in the loop shape of the balanced kernel.  Each wave keeps D 1-KiB loads in
+// flight and issues the next D before consuming the previous D.  MAP 0: workgroup b owns a contiguous 1/gridDim of W,
+// its waves interleave D-KiB pieces.  MAP 1: grid-stride (piece index = it*gridDim*WAVES + b*WAVES + wave).
+// MAP 2: wave-major grid-stride (piece = (it*WAVES + wave)*gridDim + b): the chip sweeps memory front to back.
+template <int WAVES, int D, int MAP, int OPT = 0>
+__global__ __launch_bounds__(WAVES * 64) void k_stream2(const float* w, size_t nkib, float* out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ float big[(OPT & 1) ? 40960 : 1];
+    if (OPT & 1) big[threadIdx.x] = (float)lane;
+    const size_t pieces = nkib / D;                      // D-KiB pieces
+    const size_t per_wg = pieces / gridDim.x;
+    const size_t nit = MAP == 0 ? per_wg / WAVES : pieces / ((size_t)gridDim.x * WAVES);
+    auto piece = [&](size_t it) -> size_t {
+        if (MAP == 0) return (size_t)blockIdx.x * per_wg + it * WAVES + wave;
+        if (MAP == 1) return (it * gridDim.x + blockIdx.x) * WAVES + wave;
+        return (it * WAVES + wave) * gridDim.x + blockIdx.x;
+    };
+    f32x4 cur[D], nxt[D];
+    float s = 0.f;
+    auto LD = [&](f32x4 (&r)[D], size_t it) {
+        const float* a = w + piece(it) * (size_t)D * 256 + lane * 4;
+#pragma unroll
+        for (int d = 0; d < D; ++d) r[d] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a + d * 256));
+    };
+    if (nit > 0) LD(cur, 0);
+    f32x4 accv[(OPT & 2) ? 10 : 1];
+    if (OPT & 2) for (int q = 0; q < 10; ++q) accv[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const size_t nit_w = (OPT & 4) ? nit - (size_t)(wave & 1) * 0 + (wave == 99 ? 1 : 0) : nit;   // OPT 4: loop bound in a VGPR
+    for (size_t it = 0; it < nit_w; ++it) {
+        LD(nxt, it + 1 < nit ? it + 1 : it);
+        if (OPT & 2) {          // ~80 dependent-free VALU ops per turn, like the ablated MFMA body
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int d = 0; d < D; ++d) { accv[2 * d][j] += cur[d][j] + 1.0f; accv[2 * d + 1][j] += cur[d][j] + 2.0f; }
+        }
+#pragma unroll
+        for (int d = 0; d < D; ++d) s += cur[d][d & 3];
+#pragma unroll
+        for (int d = 0; d < D; ++d) cur[d] = nxt[d];
+    }
+    if (OPT & 2) for (int q = 0; q < 10; ++q) s += accv[q][0] + accv[q][1] + accv[q][2] + accv[q][3];
+    if (OPT & 1) { __syncthreads(); s += big[(threadIdx.x * 7) & 1023]; }
+    if (s == 123.456f) out[0] = s;
+}
+
+// Streaming + activation study: as k_stream2 MAP 0 (256 x 16 waves, D weight KiB per turn), plus X 1-KiB loads per turn
+// from a small L2-resident buffer walked like the x operand (xs bytes per workgroup region).  XM: 0 = global loads issued
+// after the W loads, 1 = before them, 2 = from LDS (64 KiB ring), 3 = global with two turns of W kept in flight (A/B stages).
+template <int D, int X, int XM, int MF = 0, int WV = 16>
+__global__ __launch_bounds__(WV * 64) void k_stream3(const float* w, size_t nkib, const float* xb, size_t xkib, float* out) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const size_t pieces = nkib / D, per_wg = pieces / gridDim.x, nit = per_wg / WV;
+    __shared__ __attribute__((aligned(16))) float xl[16384];
+    if (XM == 2) {
+        for (int e = threadIdx.x; e < 4096; e += WV * 64) reinterpret_cast<float4*>(xl)[e] = reinterpret_cast<const float4*>(xb)[e];
+        __syncthreads();
+    }
+    typedef __attribute__((address_space(1))) const f32x4 gf4;
+    const float* wbase = w + ((size_t)blockIdx.x * per_wg + wave) * (size_t)D * 256 + lane * 4;
+    const float* xbase = xb + (size_t)(blockIdx.x % 5) * (xkib / 5) * 256 + lane * 4;     // 5 "members"
+    const size_t xper = xkib / 5 / X;
+    f32x4 wa[D], wb_[D], xa[X], xb_[X];
+    float s = 0.f;
+    auto LDW = [&](f32x4 (&r)[D], size_t it) {
+        const float* a = wbase + it * WV * (size_t)D * 256;
+#pragma unroll
+        for (int d = 0; d < D; ++d) r[d] = __builtin_nontemporal_load((const gf4*)(a + d * 256));
+    };
+    auto LDX = [&](f32x4 (&r)[X], size_t it) {
+        const size_t pi = (it * WV + wave) % xper;
+#pragma unroll
+        for (int d = 0; d < X; ++d) {
+            if (XM == 2) r[d] = *reinterpret_cast<const f32x4*>(xl + (((pi * X + d) & 15) * 256) + lane * 4);
+            else r[d] = *(const gf4*)(xbase + (pi * X + d) * 256);
+        }
+    };
+    f32x4 acc[MF ? D : 1][MF ? X : 1];
+    if (MF) for (int d = 0; d < D; ++d) for (int q = 0; q < X; ++q) acc[d][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto USE = [&](const f32x4 (&a)[D], const f32x4 (&x)[X]) {
+        if (MF) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int d = 0; d < D; ++d)
+#pragma unroll
+                    for (int q = 0; q < X; ++q) acc[d][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[d][j], x[q][j], acc[d][q], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int d = 0; d < D; ++d) s += a[d][0] * x[d % X][1] + a[d][2] * x[d % X][3];
+        }
+    };
+    if (XM == 3) {
+        if (nit > 0) { LDW(wa, 0); LDX(xa, 0); }
+        size_t it = 0;
+        for (; it + 1 < nit; it += 2) {
+            LDW(wb_, it + 1); LDX(xb_, it + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            USE(wa, xa);
+            __builtin_amdgcn_sched_barrier(0);
+            LDW(wa, it + 2 < nit ? it + 2 : it + 1); LDX(xa, it + 2 < nit ? it + 2 : it + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            USE(wb_, xb_);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (it < nit) USE(wa, xa);
+    } else if (XM == 4) {          // arithmetic only: operands loaded once
+        LDW(wa, 0); LDX(xa, 0);
+        for (size_t it = 0; it < nit; ++it) {
+            USE(wa, xa);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+        for (size_t it = 0; it < nit; ++it) {
+            if (XM == 1) LDX(xa, it);
+            LDW(wa, it);
+            if (XM != 1) LDX(xa, it);
+            __builtin_amdgcn_sched_barrier(0);
+            USE(wa, xa);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (MF) for (int d = 0; d < D; ++d) for (int q = 0; q < X; ++q) s += acc[d][q][0] + acc[d][q][1] + acc[d][q][2] + acc[d][q][3];
+    if (s == 123.456f) out[0] = s;
+}
+
+// k_var3's W-only loop and addressing (fragment-major, NF streams per workgroup, clamped group index, cur<-next copies),
+// nothing else.  VAR 1: also carries 40 accumulator registers updated per turn like the ablated MFMA body.
+template <int NF, int WAVES, int VAR>
+__global__ __launch_bounds__(WAVES * 64) void k_stream5(const float* wp_, int nch, int total, float* out) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int f0 = blockIdx.x * NF;
+    const float* wbase[NF];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) wbase[f] = wp_ + (size_t)min(f0 + f, total - 1) * (size_t)nch * 256 + lane * 4;
+    const int ngroups = nch, ngw = ngroups > wave ? (ngroups - wave + WAVES - 1) / WAVES : 0, glast = ngroups - 1;
+    float4 wc[NF], wn[NF];
+    f32x4 acc[NF][2];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) { acc[f][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[f][1] = acc[f][0]; }
+    auto LDW = [&](float4 (&w)[NF], int grp) {
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+            f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(wbase[f] + (size_t)grp * 256));
+            w[f] = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    };
+    if (ngw > 0) LDW(wc, min(wave, glast));
+    for (int i = 0; i < ngw; ++i) {
+        LDW(wn, min(wave + (i + 1 < ngw ? i + 1 : i) * WAVES, glast));
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+            acc[f][0][0] += wc[f].x; acc[f][0][1] += wc[f].y; acc[f][0][2] += wc[f].z; acc[f][0][3] += wc[f].w;
+            if (VAR == 1) { acc[f][1][0] += wc[f].x + 1.f; acc[f][1][1] += wc[f].y + 1.f; acc[f][1][2] += wc[f].z + 1.f; acc[f][1][3] += wc[f].w + 1.f; }
+        }
+#pragma unroll
+        for (int f = 0; f < NF; ++f) wc[f] = wn[f];
+    }
+    float t = 0.f;
+#pragma unroll
+    for (int f = 0; f < NF; ++f) t += acc[f][0][0] + acc[f][0][1] + acc[f][0][2] + acc[f][0][3] + acc[f][1][0] + acc[f][1][3];
+    if (t == 123.456f) out[0] = t;
 }
 
 __global__ void k_pack(const float* src, float* dst, int R, int K) {  // [R][K] -> [R/16][K/16][64][4]
@@ -318,16 +484,30 @@ __global__ __launch_bounds__(WAVES * 64) void k_var3(P p, int G) {
         for (int u = 0; u < U; ++u)
 #pragma unroll
             for (int f = 0; f < NF; ++f) {
-                const float* a = wbase[f] + ((size_t)grp * U + u) * 256;
+                // ABL 4/5: chunk-major weight image (timing only: the data is not repacked) -- block (chunk c, fragment fr) at
+                // (c*total + fr) KiB, so a wave's NF loads are contiguous and the chip sweeps memory front to back
+                const float* a = (ABL == 4 || ABL == 5 || ABL == 7)
+                    ? p.wp + ((size_t)(grp * U + u) * total + min(f0 + f, total - 1)) * 256 + lane * 4
+                    : wbase[f] + ((size_t)grp * U + u) * 256;
                 if (NT) { f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a)); w[u][f] = make_float4(v[0], v[1], v[2], v[3]); }
                 else w[u][f] = *reinterpret_cast<const float4*>(a);
             }
     };
+    // ABL == 3: x comes from a 64 KiB LDS ring filled once (timing ablation: no global x loads in the loop)
+    __shared__ __attribute__((aligned(16))) float red[WAVES][NF][MT][4][64];
+    float* xl = &red[0][0][0][0][0];       // the reduction buffer is free until the loop ends
+    if (ABL == 3) {
+        for (int e = tid; e < 16384 / 4; e += WAVES * 64) reinterpret_cast<float4*>(xl)[e] = reinterpret_cast<const float4*>(p.xp)[e];
+        __syncthreads();
+    }
     auto LDX = [&](float4 (&x)[U][MT], const float* const (&xb)[MT], int grp) {
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) x[u][mt] = *reinterpret_cast<const float4*>(xb[mt] + ((size_t)grp * U + u) * 256);
+            for (int mt = 0; mt < MT; ++mt) {
+                if (ABL == 3) x[u][mt] = *reinterpret_cast<const float4*>(xl + (((grp * U + u) & 15) * MT + mt) * 256 + lane * 4);
+                else x[u][mt] = *reinterpret_cast<const float4*>(xb[mt] + ((size_t)grp * U + u) * 256);
+            }
     };
     if (uniform) {
         // ROT: rotate this workgroup's k order so that workgroups are at different offsets of their fragments
@@ -337,7 +517,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_var3(P p, int G) {
         for (int i = 0; i < ngw; ++i) {
             const int gn = G_OF(i + 1 < ngw ? i + 1 : i);
             LDW(wn, gn);
-            if (ABL != 2) LDX(xn, xA, gn);
+            if (ABL != 2 && ABL != 5 && ABL != 6 && ABL != 7) LDX(xn, xA, gn);
 #pragma unroll
             for (int u = 0; u < U; ++u)
 #pragma unroll
@@ -348,8 +528,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_var3(P p, int G) {
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt) {
                             const float xv = j == 0 ? xc[u][mt].x : j == 1 ? xc[u][mt].y : j == 2 ? xc[u][mt].z : xc[u][mt].w;
-                            if (ABL == 0) acc[f][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, xv, acc[f][mt], 0, 0, 0);
-                            else if (j == 0) acc[f][mt][0] += wv + xv;
+                            if (ABL == 0 || ABL == 3 || ABL == 4) acc[f][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, xv, acc[f][mt], 0, 0, 0);
+                            else acc[f][mt][j] += wv + xv;          // every component used: the loads stay 16 bytes wide
                         }
                     }
 #pragma unroll
@@ -383,7 +563,16 @@ __global__ __launch_bounds__(WAVES * 64) void k_var3(P p, int G) {
                     }
         }
     }
-    __shared__ float red[WAVES][NF][MT][4][64];
+    if (ABL == 3) __syncthreads();
+    if (ABL == 6 || ABL == 7) {
+        float t = 0.f;
+#pragma unroll
+        for (int f = 0; f < NF; ++f)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) t += acc[f][mt][0];
+        if (t == 123.456f) p.out[0] = t;
+        return;
+    }
 #pragma unroll
     for (int f = 0; f < NF; ++f)
 #pragma unroll
@@ -598,6 +787,14 @@ int main(int argc, char** argv) {
         {"q2 NF5 W16 U1 nt W only      ", launch3<2, 5, 16, 1, true, 2>},
         {"q3 NF5 W16 U1 nt full (=p4)  ", launch3<2, 5, 16, 1, true, 0>},
         {"q4 NF5 W8 U2 nt W only       ", launch3<2, 5, 8, 2, true, 2>},
+        {"q6 NF5 W16 U1 nt x from LDS  ", launch3<2, 5, 16, 1, true, 3>},
+        {"q8 NF5 W16 U1 nt chunk-major ", launch3<2, 5, 16, 1, true, 4>},
+        {"q12 W-only no epilogue       ", launch3<2, 5, 16, 1, true, 6>},
+        {"q13 W-only chunkmaj no epilog", launch3<2, 5, 16, 1, true, 7>},
+        {"q9 NF5 W16 U1 nt chunk-maj W ", launch3<2, 5, 16, 1, true, 5>},
+        {"q10 NF5 W8 U2 nt chunk-major ", launch3<2, 5, 8, 2, true, 4>},
+        {"q11 NF4 W16 U2 nt chunk-major", launch3<2, 4, 16, 2, true, 4>},
+        {"q7 NF5 W8 U2 nt x from LDS   ", launch3<2, 5, 8, 2, true, 3>},
         {"q5 NF5 W8 U2 nt loads only   ", launch3<2, 5, 8, 2, true, 1>},
         {"p1 NF5 W8 U2 nt persistent   ", launch3<2, 5, 8, 2, true>},
         {"p2 NF5 W8 U1 nt persistent   ", launch3<2, 5, 8, 1, true>},
@@ -671,6 +868,95 @@ int main(int argc, char** argv) {
             CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
             if (r >= 2) times[vars.size() + nt].push_back(ms / 4);
+        }
+    }
+    if (argc > 3 && argv[3][0] == 'T') {      // per-workgroup timing of the library kernel (MODE 0)
+        long long* dbg; CK(hipMalloc(&dbg, 4096 * 3 * 8)); CK(hipMemset(dbg, 0, 4096 * 3 * 8));
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(nd_dbg_times), &dbg, sizeof dbg));
+        for (int rep = 0; rep < 3; ++rep) launch_lib<0, 0>(p, G, st);
+        CK(hipStreamSynchronize(st));
+        std::vector<long long> h(4096 * 3);
+        CK(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
+        const SkinnyLaunch L = nd_skinny_launch<0>(K, N, M, G);
+        long long tmin = 1LL << 62; for (unsigned b = 0; b < L.grid.x; ++b) tmin = std::min(tmin, h[b * 3]);
+        printf("grid %u workgroups; per-WG (start, loop, total) in us relative to the first start [100 MHz clock]\n", L.grid.x);
+        std::vector<std::pair<double, unsigned>> tot;
+        for (unsigned b = 0; b < L.grid.x; ++b) tot.push_back({(h[b * 3 + 2] - tmin) / 100.0, b});
+        std::sort(tot.begin(), tot.end());
+        auto pr = [&](unsigned b) { printf("  wg %4u: start %6.2f  loop-end %6.2f  end %6.2f\n", b, (h[b * 3] - tmin) / 100.0, (h[b * 3 + 1] - tmin) / 100.0, (h[b * 3 + 2] - tmin) / 100.0); };
+        printf("earliest finishers:\n"); for (int i = 0; i < 4; ++i) pr(tot[i].second);
+        printf("median:\n"); pr(tot[tot.size() / 2].second);
+        printf("latest finishers:\n"); for (size_t i = tot.size() - 8; i < tot.size(); ++i) pr(tot[i].second);
+        return 0;
+    }
+    if (argc > 3 && argv[3][0] == 's') {
+        struct SV { const char* name; void (*fn)(const float*, size_t, float*, hipStream_t); };
+        const size_t nkib = wsz / 256;
+#define SVL(W_, D_, M_, G_) [](const float* ww, size_t nk, float* o, hipStream_t s_) { hipLaunchKernelGGL((k_stream2<W_, D_, M_>), dim3(G_), dim3(W_ * 64), 0, s_, ww, nk, o); }
+        SV svs[] = {
+            {"s 256wg x16w D5 contiguous ", SVL(16, 5, 0, 256)}, {"s 256wg x16w D5 gridstride ", SVL(16, 5, 1, 256)},
+            {"s 256wg x16w D5 wave-major ", SVL(16, 5, 2, 256)}, {"s 512wg x8w  D5 contiguous ", SVL(8, 5, 0, 512)},
+            {"s 1024wg x4w D5 contiguous ", SVL(4, 5, 0, 1024)}, {"s 1024wg x4w D5 gridstride ", SVL(4, 5, 1, 1024)},
+            {"s 256wg x16w D10 contiguous", SVL(16, 10, 0, 256)}, {"s 256wg x16w D2 contiguous ", SVL(16, 2, 0, 256)},
+            {"s 256wg x16w D2 gridstride ", SVL(16, 2, 1, 256)}, {"s 512wg x16w D5 contiguous ", SVL(16, 5, 0, 512)},
+            {"s 2048wg x4w D4 gridstride ", SVL(4, 4, 1, 2048)}, {"s 256wg x8w D8 contiguous  ", SVL(8, 8, 0, 256)},
+            {"s 1280wg x4w D4 contiguous ", SVL(4, 4, 0, 1280)}, {"s 256wg x16w D1 gridstride ", SVL(16, 1, 1, 256)},
+            {"s5 frag-major NF5 W16        ", [](const float* ww, size_t nk, float* o, hipStream_t s_) { hipLaunchKernelGGL((k_stream5<5, 16, 0>), dim3(256), dim3(1024), 0, s_, ww, 256, 1280, o); }},
+            {"s5 frag-major NF5 W16 +acc   ", [](const float* ww, size_t nk, float* o, hipStream_t s_) { hipLaunchKernelGGL((k_stream5<5, 16, 1>), dim3(256), dim3(1024), 0, s_, ww, 256, 1280, o); }},
+            {"s5 frag-major NF1 W16 1280wg ", [](const float* ww, size_t nk, float* o, hipStream_t s_) { hipLaunchKernelGGL((k_stream5<1, 16, 0>), dim3(1280), dim3(1024), 0, s_, ww, 256, 1280, o); }},
+            {"s 256wg x16w D5 contig +VALU   ", [](const float* ww, size_t nk, float* o, hipStream_t s_) { hipLaunchKernelGGL((k_stream2<16, 5, 0, 2>), dim3(256), dim3(1024), 0, s_, ww, nk, o); }},
+            {"s 256wg x16w D5 contig +divloop", [](const float* ww, size_t nk, float* o, hipStream_t s_) { hipLaunchKernelGGL((k_stream2<16, 5, 0, 4>), dim3(256), dim3(1024), 0, s_, ww, nk, o); }},
+            {"s 256wg x16w D5 contig +both   ", [](const float* ww, size_t nk, float* o, hipStream_t s_) { hipLaunchKernelGGL((k_stream2<16, 5, 0, 6>), dim3(256), dim3(1024), 0, s_, ww, nk, o); }},
+            {"s 256wg x16w D5 contig +LDS160K", [](const float* ww, size_t nk, float* o, hipStream_t s_) { hipLaunchKernelGGL((k_stream2<16, 5, 0, 1>), dim3(256), dim3(1024), 0, s_, ww, nk, o); }},
+        };
+        if (argv[3][1] == 'x') {
+            struct SX { const char* name; void (*fn)(const float*, size_t, const float*, size_t, float*, hipStream_t); };
+            const size_t xkib = (size_t)G * M * K / 256;      // the real x operand: G members x [M][K] fp32
+#define SXL(D_, X_, XM_) [](const float* ww, size_t nk, const float* xx, size_t xk, float* o, hipStream_t s_) { hipLaunchKernelGGL((k_stream3<D_, X_, XM_>), dim3(256), dim3(1024), 0, s_, ww, nk, xx, xk, o); }
+            SX sxs[] = {
+                {"sx D5 X2 global after W    ", SXL(5, 2, 0)}, {"sx D5 X2 global before W   ", SXL(5, 2, 1)},
+                {"sx D5 X2 from LDS          ", SXL(5, 2, 2)}, {"sx D5 X2 global A/B stages ", SXL(5, 2, 3)},
+                {"sx D5 X1 global after W    ", SXL(5, 1, 0)}, {"sx D10 X2 global after W   ", SXL(10, 2, 0)},
+                {"sx D10 X4 global after W   ", SXL(10, 4, 0)}, {"sx D5 X4 global after W    ", SXL(5, 4, 0)},
+                {"sx D5 X5 from LDS          ", SXL(5, 5, 2)},
+                {"sx D5 X2 A/B + MFMA 16w    ", [](const float* ww, size_t nk, const float* xx, size_t xk, float* o, hipStream_t s_) { hipLaunchKernelGGL((k_stream3<5, 2, 3, 1, 16>), dim3(256), dim3(1024), 0, s_, ww, nk, xx, xk, o); }},
+                {"sx D5 X2 1stage + MFMA 16w ", [](const float* ww, size_t nk, const float* xx, size_t xk, float* o, hipStream_t s_) { hipLaunchKernelGGL((k_stream3<5, 2, 0, 1, 16>), dim3(256), dim3(1024), 0, s_, ww, nk, xx, xk, o); }},
+                {"sx D5 X2 A/B + MFMA 8w     ", [](const float* ww, size_t nk, const float* xx, size_t xk, float* o, hipStream_t s_) { hipLaunchKernelGGL((k_stream3<5, 2, 3, 1, 8>), dim3(256), dim3(512), 0, s_, ww, nk, xx, xk, o); }},
+                {"sx D5 X2 1stage + MFMA 8w  ", [](const float* ww, size_t nk, const float* xx, size_t xk, float* o, hipStream_t s_) { hipLaunchKernelGGL((k_stream3<5, 2, 0, 1, 8>), dim3(256), dim3(512), 0, s_, ww, nk, xx, xk, o); }},
+                {"sx D5 X2 MFMA only 16w     ", [](const float* ww, size_t nk, const float* xx, size_t xk, float* o, hipStream_t s_) { hipLaunchKernelGGL((k_stream3<5, 2, 4, 1, 16>), dim3(256), dim3(1024), 0, s_, ww, nk, xx, xk, o); }},
+                {"sx D5 X2 MFMA only 8w      ", [](const float* ww, size_t nk, const float* xx, size_t xk, float* o, hipStream_t s_) { hipLaunchKernelGGL((k_stream3<5, 2, 4, 1, 8>), dim3(256), dim3(512), 0, s_, ww, nk, xx, xk, o); }},
+                {"sx D5 X2 MFMA only 4w      ", [](const float* ww, size_t nk, const float* xx, size_t xk, float* o, hipStream_t s_) { hipLaunchKernelGGL((k_stream3<5, 2, 4, 1, 4>), dim3(256), dim3(256), 0, s_, ww, nk, xx, xk, o); }},
+                {"sx D5 X2 A/B + MFMA 4w     ", [](const float* ww, size_t nk, const float* xx, size_t xk, float* o, hipStream_t s_) { hipLaunchKernelGGL((k_stream3<5, 2, 3, 1, 4>), dim3(256), dim3(256), 0, s_, ww, nk, xx, xk, o); }},
+                {"sx D10 X2 A/B + MFMA 4w    ", [](const float* ww, size_t nk, const float* xx, size_t xk, float* o, hipStream_t s_) { hipLaunchKernelGGL((k_stream3<10, 2, 3, 1, 4>), dim3(256), dim3(256), 0, s_, ww, nk, xx, xk, o); }},
+                {"sx D10 X2 A/B + MFMA 8w    ", [](const float* ww, size_t nk, const float* xx, size_t xk, float* o, hipStream_t s_) { hipLaunchKernelGGL((k_stream3<10, 2, 3, 1, 8>), dim3(256), dim3(512), 0, s_, ww, nk, xx, xk, o); }},
+                {"sx D5 X2 A/B no MFMA 8w    ", [](const float* ww, size_t nk, const float* xx, size_t xk, float* o, hipStream_t s_) { hipLaunchKernelGGL((k_stream3<5, 2, 3, 0, 8>), dim3(256), dim3(512), 0, s_, ww, nk, xx, xk, o); }},
+            };
+            for (auto& sv : sxs) {
+                std::vector<float> tt;
+                for (int r = 0; r < rounds + 2; ++r) {
+                    CK(hipEventRecord(e0, st));
+                    for (int rep = 0; rep < 4; ++rep) sv.fn(w, nkib, p.xp, xkib, out, st);
+                    CK(hipEventRecord(e1, st));
+                    CK(hipEventSynchronize(e1));
+                    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                    if (r >= 2) tt.push_back(ms / 4);
+                }
+                std::sort(tt.begin(), tt.end());
+                printf("%-32s median %8.1f us  min %8.1f us   %7.0f GB/s (median)\n", sv.name, tt[tt.size() / 2] * 1e3, tt[0] * 1e3, wbytes / (tt[tt.size() / 2] * 1e-3) / 1e9);
+            }
+        } else
+        for (auto& sv : svs) {
+            std::vector<float> tt;
+            for (int r = 0; r < rounds + 2; ++r) {
+                CK(hipEventRecord(e0, st));
+                for (int rep = 0; rep < 4; ++rep) sv.fn(argv[3][1] == 'p' ? wp : w, nkib, out, st);
+                CK(hipEventRecord(e1, st));
+                CK(hipEventSynchronize(e1));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                if (r >= 2) tt.push_back(ms / 4);
+            }
+            std::sort(tt.begin(), tt.end());
+            printf("%-32s median %8.1f us  min %8.1f us   %7.0f GB/s (median)\n", sv.name, tt[tt.size() / 2] * 1e3, tt[0] * 1e3, wbytes / (tt[tt.size() / 2] * 1e-3) / 1e9);
         }
     }
     printf("G=%d members, M=%d, K=N=%d, weight bytes per launch = %.1f MB\n", G, M, K, wbytes / 1e6);
