@@ -480,16 +480,30 @@ static inline SkinnyLaunch nd_skinny_launch(int K, int N, int M, int nm, int hal
     if (wpm < 1) wpm = 1;
     if (wpm > nfr) wpm = nfr;
     while ((nfr + wpm - 1) / wpm > nfmax) ++wpm;
-    const int nf = (nfr + wpm - 1) / wpm;          // = base + (nfr % wpm != 0): the kernel's fragment slots
-    const int gx = nm * wpm;
     int S = 1, cps = nch;
     if (MODE == 2) {
-        S = 256 / (gx * mgroups);
-        if (S < 1) S = 1;
-        while (S > 1 && nch / S < 64) --S;          // keep every slab >= 64 chunks (1024 floats) deep
+        // split-K: k-slabs fill the CUs, so fragments per workgroup can stay high (each workgroup streams the x of its
+        // slab once per NF weight fragments: at NF = 1 that is twice the weight bytes).  Pick (workgroups per member, S)
+        // by cost = (1 + 0.3*MT/nf) / (fraction of the 256 CUs busy).
+        double best = 1e30;
+        int bw = wpm, bs = 1;
+        for (int nfc = nfmax; nfc >= 1; --nfc) {
+            const int w = (nfr + nfc - 1) / nfc;
+            const int wgs = nm * w * mgroups;
+            int sc = wgs >= 256 ? 1 : 256 / wgs;
+            while (sc > 1 && nch / sc < 64) --sc;          // keep every slab >= 64 chunks deep
+            const long tot = (long)wgs * sc;
+            const double util = tot >= 256 ? (double)tot / (256.0 * ((tot + 255) / 256)) : tot / 256.0;
+            const double nfe = (double)nfr / w;
+            const double cost = (1.0 + 0.3 * mt / nfe) / util;
+            if (cost < best - 1e-9) { best = cost; bw = w; bs = sc; }
+        }
+        wpm = bw; S = bs;
         cps = (nch + S - 1) / S;
         S = (nch + cps - 1) / cps;
     }
+    const int nf = (nfr + wpm - 1) / wpm;          // = base + (nfr % wpm != 0): the kernel's fragment slots
+    const int gx = nm * wpm;
     const bool nt = (double)nm * N * (double)K * (half ? 2.0 : 4.0) > 160e6;
     SkinnyLaunch L{nullptr, dim3(gx, mgroups, S), dim3(256), cps, S};
 #define ND_SK(MTV, NFV, WV, UV)                                                                                     \
