@@ -187,7 +187,7 @@ def main():
         "config": {"workload": f"K={K} members, T={T} steps, B={B} images/GPU (3x224x224), mc={mc}, D=150528, F=H=4096; "
                                "whole hot path per step: ViT-prefix+mapping MLPs, encoder hoist, K*T reverse steps, aggregation",
                    "global_batch": B * world, "parallelism": f"dp{world} (batch-sharded, all K members per GPU, one all-gather)"},
-        "roofline": {"bound": "hbm", "kernel": "k_skinny<2,5,16,1,*> (lin2 / lin3+lin4 ConditionalLinear blocks, K members per launch)",
+        "roofline": {"bound": "hbm", "kernel": "k_skinny<2,6,4,2,{0,1},true> (lin2 / lin3+lin4 ConditionalLinear blocks, K members per launch)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
                      "traffic": traffic, "alg_bytes_per_launch": alg_bytes, "avg_launch_us": avg_us,
                      "probe": {"head_us": head_us, "lin2_us": lin2_us, "lin3_us": lin3_us, "steps_probed": n_probe}},
