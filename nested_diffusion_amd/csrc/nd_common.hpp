@@ -28,8 +28,16 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 #define ND_ACT_GELU 3
 
 __device__ __forceinline__ float nd_softplus(float x) {
-    // torch softplus(beta=1, threshold=20): x if x > 20 else log1p(exp(x))
-    return x > 20.0f ? x : log1pf(expf(x));
+    // torch softplus(beta=1, threshold=20): x if x > 20 else log1p(exp(x)).
+    // Evaluated as max(x,0) + log1p(u), u = exp(-|x|) in (0,1], with the compensated form
+    // log1p(u) = log(w) - ((w-1)-u)/w, w = fl(1+u)  (1-2 ulp; the correction term is ~1e-8, so an approximate reciprocal
+    // is enough).  Half the instructions of log1pf(expf(x)) (whose log1pf goes through f64 here) -- this function is the
+    // bulk of the step kernels' epilogue, which runs on one wave per SIMD with nothing to overlap it.
+    const float u = expf(-fabsf(x));
+    const float w = 1.0f + u;
+    const float c = (w - 1.0f) - u;
+    const float r = fmaxf(x, 0.0f) + (logf(w) - c * __builtin_amdgcn_rcpf(w));
+    return x > 20.0f ? x : r;
 }
 
 __device__ __forceinline__ float nd_act(float v, int act) {
@@ -328,6 +336,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_skinny(SkinnyDesc d0, const Skin
 #pragma unroll
             for (int r = 0; r < 4; ++r) red[wave][((f * MT + mt) * 4 + r) * 64 + lane] = acc[f][mt][r];
     __syncthreads();
+#ifdef ND_WG_TIMING
+    const long long dbg_t2 = wall_clock64();
+    long long dbg_t3 = dbg_t2;
+#endif
     float* const R = red[0];
     const int m0 = blockIdx.y * 16 * MT;
     if (MODE == 2) {
@@ -351,15 +363,47 @@ __global__ __launch_bounds__(WAVES * 64) void k_skinny(SkinnyDesc d0, const Skin
             }
         }
     } else {
-        for (int q = tid; q < nact * MT * 256; q += WAVES * 64) {
-            const int f = q / (MT * 256), r = (q >> 6) & 3, l = q & 63;
-            float sum = red[0][q];
+        // fully unrolled, no branches: with one wave per SIMD the only latency hiding is the instruction-level parallelism
+        // of these NF*MT*256/threads independent activations (slots f >= nact hold zeros: computed, never stored further)
+        static_assert((MT * 256) % (WAVES * 64) == 0, "epilogue assumes MT*256 is a multiple of the workgroup size");
+        constexpr int EPF = MT * 256 / (WAVES * 64);        // elements per thread and fragment
+        float ev[NF][EPF];
 #pragma unroll
-            for (int w = 1; w < WAVES; ++w) sum += red[w][q];
-            const int nl = 4 * (l >> 4) + r;
-            R[q] = ((fi0 + f) * 16 + nl < N) ? nd_act(ssc[f][nl] * sum + ssh[f][nl], eact) : 0.f;
+        for (int f = 0; f < NF; ++f)
+#pragma unroll
+            for (int jq = 0; jq < EPF; ++jq) {
+                const int q = f * MT * 256 + jq * WAVES * 64 + tid;
+                float sum = red[0][q];
+#pragma unroll
+                for (int w = 1; w < WAVES; ++w) sum += red[w][q];
+                const int nl = 4 * ((q & 63) >> 4) + ((q >> 6) & 3);
+                ev[f][jq] = ssc[f][nl] * sum + ssh[f][nl];
+            }
+        // the activation is uniform: branch once, then a straight run of independent evaluations
+        auto activate = [&](auto fn) {
+#pragma unroll
+            for (int f = 0; f < NF; ++f)
+#pragma unroll
+                for (int jq = 0; jq < EPF; ++jq) ev[f][jq] = fn(ev[f][jq]);
+        };
+        switch (eact) {
+            case ND_ACT_SOFTPLUS: activate([](float v) { return nd_softplus(v); }); break;
+            case ND_ACT_RELU: activate([](float v) { return v > 0.0f ? v : 0.0f; }); break;
+            case ND_ACT_GELU: activate([](float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }); break;
+            default: break;
         }
+#pragma unroll
+        for (int f = 0; f < NF; ++f)
+#pragma unroll
+            for (int jq = 0; jq < EPF; ++jq) {
+                const int q = f * MT * 256 + jq * WAVES * 64 + tid;
+                const int nl = 4 * ((q & 63) >> 4) + ((q >> 6) & 3);
+                R[q] = ((fi0 + f) * 16 + nl < N) ? ev[f][jq] : 0.f;
+            }
         __syncthreads();
+#ifdef ND_WG_TIMING
+        dbg_t3 = wall_clock64();
+#endif
         if (MODE == 0) {
             if (epacked == 2) {
                 // frag32h: a fragment's 16 columns are k-groups (nfi&1)*2 + {0,1} of block (m-tile, nfi/2): lanes
@@ -411,6 +455,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_skinny(SkinnyDesc d0, const Skin
     if (tid == 0 && nd_dbg_times) {
         long long* q = nd_dbg_times + (size_t)blockIdx.x * 3;
         q[0] = dbg_t0; q[1] = dbg_t1; q[2] = wall_clock64();
+        long long* q2 = nd_dbg_times + (size_t)(4096 + blockIdx.x) * 3;
+        q2[0] = dbg_t2; q2[1] = dbg_t3; q2[2] = 0;
     }
 #endif
 }

@@ -871,11 +871,11 @@ int main(int argc, char** argv) {
         }
     }
     if (argc > 3 && argv[3][0] == 'T') {      // per-workgroup timing of the library kernel (MODE 0)
-        long long* dbg; CK(hipMalloc(&dbg, 4096 * 3 * 8)); CK(hipMemset(dbg, 0, 4096 * 3 * 8));
+        long long* dbg; CK(hipMalloc(&dbg, 8192 * 3 * 8)); CK(hipMemset(dbg, 0, 8192 * 3 * 8));
         CK(hipMemcpyToSymbol(HIP_SYMBOL(nd_dbg_times), &dbg, sizeof dbg));
         for (int rep = 0; rep < 3; ++rep) launch_lib<0, 0>(p, G, st);
         CK(hipStreamSynchronize(st));
-        std::vector<long long> h(4096 * 3);
+        std::vector<long long> h(8192 * 3);
         CK(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
         const SkinnyLaunch L = nd_skinny_launch<0>(K, N, M, G);
         long long tmin = 1LL << 62; for (unsigned b = 0; b < L.grid.x; ++b) tmin = std::min(tmin, h[b * 3]);
@@ -883,7 +883,7 @@ int main(int argc, char** argv) {
         std::vector<std::pair<double, unsigned>> tot;
         for (unsigned b = 0; b < L.grid.x; ++b) tot.push_back({(h[b * 3 + 2] - tmin) / 100.0, b});
         std::sort(tot.begin(), tot.end());
-        auto pr = [&](unsigned b) { printf("  wg %4u: start %6.2f  loop-end %6.2f  end %6.2f\n", b, (h[b * 3] - tmin) / 100.0, (h[b * 3 + 1] - tmin) / 100.0, (h[b * 3 + 2] - tmin) / 100.0); };
+        auto pr = [&](unsigned b) { printf("  wg %4u: start %6.2f  loop-end %6.2f  red-written %6.2f  activated %6.2f  end %6.2f\n", b, (h[b * 3] - tmin) / 100.0, (h[b * 3 + 1] - tmin) / 100.0, (h[(4096 + b) * 3] - tmin) / 100.0, (h[(4096 + b) * 3 + 1] - tmin) / 100.0, (h[b * 3 + 2] - tmin) / 100.0); };
         printf("earliest finishers:\n"); for (int i = 0; i < 4; ++i) pr(tot[i].second);
         printf("median:\n"); pr(tot[tot.size() / 2].second);
         printf("latest finishers:\n"); for (size_t i = tot.size() - 8; i < tot.size(); ++i) pr(tot[i].second);
