@@ -135,7 +135,8 @@ int nd_sample(nd_handle h, int member0, int n_members, const float *yhat_dev, co
  * nd_sample graph (or eager loop) get hipEvent record nodes around their three kernels on the launch
  * stream.  nd_profile_read (after the stream is synchronised) returns the mean duration in
  * microseconds of the last nd_sample's probed launches: out_us[0] step head, [1] lin2 block,
- * [2] lin3+lin4 block; *n_samples = probed steps. */
+ * [2] lin3+lin4 block, [3] an EMPTY interval (two record nodes back to back): what one record node adds to every
+ * interval, to be subtracted when a kernel's own duration is wanted; *n_samples = probed steps.  out_us holds 4 floats. */
 int nd_set_profiling(nd_handle h, int enable);
 int nd_profile_read(nd_handle h, float *out_us, int *n_samples);
 

@@ -336,7 +336,7 @@ struct nd_handle_s {
     std::map<GraphKey, hipGraphExec_t> graphs;
     int encoded_B = -1;
     bool profiling = false;
-    std::vector<hipEvent_t> probe_events;   // 4 per probed step: e0 | head | e1 | lin2 | e2 | lin3 | e3
+    std::vector<hipEvent_t> probe_events;   // 5 per probed step: e0 | head | e1 | lin2 | e2 | lin3 | e3 | (nothing) | e4
     int probe_steps = 0;
 };
 
@@ -600,15 +600,15 @@ extern "C" int nd_set_profiling(nd_handle h, int enable) {
 
 extern "C" int nd_profile_read(nd_handle h, float* out_us, int* n_samples) {
     if (!h || !out_us || !n_samples) return nd_set_err(ND_ERR_ARG, "NULL argument");
-    double acc[3] = {0, 0, 0};
+    double acc[4] = {0, 0, 0, 0};
     const int n = h->probe_steps;
     for (int s = 0; s < n; ++s)
-        for (int k = 0; k < 3; ++k) {
+        for (int k = 0; k < 4; ++k) {
             float ms = 0.f;
-            HIP_CHECK(hipEventElapsedTime(&ms, h->probe_events[4 * s + k], h->probe_events[4 * s + k + 1]));
+            HIP_CHECK(hipEventElapsedTime(&ms, h->probe_events[5 * s + k], h->probe_events[5 * s + k + 1]));
             acc[k] += ms * 1000.0;
         }
-    for (int k = 0; k < 3; ++k) out_us[k] = n ? (float)(acc[k] / n) : 0.f;
+    for (int k = 0; k < 4; ++k) out_us[k] = n ? (float)(acc[k] / n) : 0.f;
     *n_samples = n;
     return ND_OK;
 }
@@ -715,9 +715,9 @@ static hipError_t emit_loop(nd_handle_s* h, Emitter& em, int m0, int nm, StepIO 
     // probes: up to 8 steps spread over the loop (never step 0: its head is the cheap INIT form)
     const int want = h->profiling ? (T - 1 < 8 ? T - 1 : 8) : 0;
     const int stride = want > 0 ? (T - 1) / want : 0;
-    if ((int)h->probe_events.size() < 4 * want) {
+    if ((int)h->probe_events.size() < 5 * want) {
         const size_t old = h->probe_events.size();
-        h->probe_events.resize(4 * want);
+        h->probe_events.resize(5 * want);
         for (size_t e = old; e < h->probe_events.size(); ++e)
             if (hipEventCreate(&h->probe_events[e]) != hipSuccess) return hipErrorOutOfMemory;
     }
@@ -725,7 +725,7 @@ static hipError_t emit_loop(nd_handle_s* h, Emitter& em, int m0, int nm, StepIO 
     for (int i = 0; i < T; ++i) {
         int t = T - 1 - i, t_prev = t + 1, mode = (i == 0) ? ND_HEAD_INIT : ND_HEAD_UPDATE, istep = i;
         const bool probe = want > 0 && i >= 1 && probed < want && ((i - 1) % stride) == stride / 2;
-        hipEvent_t* ev = probe ? &h->probe_events[4 * probed] : nullptr;
+        hipEvent_t* ev = probe ? &h->probe_events[5 * probed] : nullptr;
         if (probe) em.record(ev[0]);
         void* ah[] = {&mdev, &io, &mode, &istep, &t_prev, &t, &B, &M, &maxM, &F, &NT, &Tn};
         em.emit(head_fn(C), ghead, dim3(256), ah);
@@ -735,7 +735,7 @@ static hipError_t emit_loop(nd_handle_s* h, Emitter& em, int m0, int nm, StepIO 
         if (probe) em.record(ev[2]);
         void* a3[] = {&d0, &t3, &nm, &M, &t, &cps3};
         em.emit(L3.fn, L3.grid, L3.block, a3);
-        if (probe) { em.record(ev[3]); ++probed; }
+        if (probe) { em.record(ev[3]); em.record(ev[4]); ++probed; }     // e3 -> e4 brackets nothing: the cost of a record node itself
     }
     h->probe_steps = probed;
     int eps_only = 0, par_cur = (T - 1) & 1;

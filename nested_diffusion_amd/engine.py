@@ -140,11 +140,13 @@ class EnsembleEngine:
         check(self.lib.nd_set_profiling(self.h, 1 if enable else 0), "nd_set_profiling")
 
     def profile_read(self):
-        """(head_us, lin2_us, lin3_us, n_probed_steps) of the last sample(); synchronises the stream."""
+        """(head_us, lin2_us, lin3_us, n_probed_steps) of the last sample(); synchronises the stream.
+        self.probe_overhead_us = the measured empty interval (cost of a record node), included in all three."""
         torch.cuda.current_stream(self.device).synchronize()
-        us = (C.c_float * 3)()
+        us = (C.c_float * 4)()
         n = C.c_int(0)
         check(self.lib.nd_profile_read(self.h, us, C.byref(n)), "nd_profile_read")
+        self.probe_overhead_us = float(us[3])
         return float(us[0]), float(us[1]), float(us[2]), int(n.value)
 
     def static_buffers(self, n_members: int, B: int, mc: int, T: int, seq: bool) -> Dict[str, torch.Tensor]:
