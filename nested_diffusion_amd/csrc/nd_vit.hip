@@ -439,10 +439,12 @@ __global__ __launch_bounds__(256, MINW) void k_attention_d64(const float* __rest
 template <int NF>
 __global__ __launch_bounds__(NF * 64) void k_attention_lds(const float* __restrict__ qkv, float* __restrict__ out, int B, int N,
                                                             int heads) {
+    // grid.y query splits: a workgroup of blockDim.x/64 waves stages the whole K and V of its (image, head) and owns the
+    // query fragments blockIdx.y*waves .. +waves-1 (finer workgroups: less idle tail on 256 CUs, fewer waves per SIMD)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sK = smem;                       // [16*NF][AT_LD]
     float* sV = smem + 16 * NF * AT_LD;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = blockIdx.y * (blockDim.x >> 6) + (tid >> 6);
     const int bh = blockIdx.x, b = bh / heads, hd = bh % heads;
     const int Cm = heads * 64;
     const size_t rs = (size_t)3 * Cm;
@@ -450,15 +452,27 @@ __global__ __launch_bounds__(NF * 64) void k_attention_lds(const float* __restri
     const float* qb = base;
     const float* kb = base + Cm;
     const float* vb = base + 2 * Cm;
-    for (int e = tid; e < 16 * NF * 16; e += NF * 64) {          // 16 float4 per 64-float row
-        const int row = e >> 4, c4 = (e & 15) * 4;
-        float4 k4 = make_float4(0.f, 0.f, 0.f, 0.f), v4 = k4;
-        if (row < N) {
-            k4 = *reinterpret_cast<const float4*>(kb + (size_t)row * rs + c4);
-            v4 = *reinterpret_cast<const float4*>(vb + (size_t)row * rs + c4);
+    // staging: four rows' worth of loads in flight per thread before the LDS writes (one load per trip would expose the
+    // L2 latency ceil(3328 / threads) times)
+    for (int e0 = tid; e0 < 16 * NF * 16; e0 += 4 * blockDim.x) {     // 16 float4 per 64-float row
+        float4 k4[4], v4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + u * blockDim.x, row = e >> 4, c4 = (e & 15) * 4;
+            k4[u] = make_float4(0.f, 0.f, 0.f, 0.f); v4[u] = k4[u];
+            if (e < 16 * NF * 16 && row < N) {
+                k4[u] = *reinterpret_cast<const float4*>(kb + (size_t)row * rs + c4);
+                v4[u] = *reinterpret_cast<const float4*>(vb + (size_t)row * rs + c4);
+            }
         }
-        *reinterpret_cast<float4*>(sK + row * AT_LD + c4) = k4;
-        *reinterpret_cast<float4*>(sV + row * AT_LD + c4) = v4;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + u * blockDim.x, row = e >> 4, c4 = (e & 15) * 4;
+            if (e < 16 * NF * 16) {
+                *reinterpret_cast<float4*>(sK + row * AT_LD + c4) = k4[u];
+                *reinterpret_cast<float4*>(sV + row * AT_LD + c4) = v4[u];
+            }
+        }
     }
     const int g = lane >> 4, li = lane & 15;
     const int qrow = min(wave * 16 + li, N - 1);
@@ -535,7 +549,13 @@ static hipError_t launch_attention_lds(const float* qkv, float* out, int B, int 
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_attention_lds<NF>), dim3(B * heads), dim3(NF * 64), lds, st, qkv, out, B, N, heads);
+    // query splits: enough workgroups for >= 3 per CU when the problem allows, at least 2 waves each
+    static const int qs_env = getenv("ND_ATT_QS") ? atoi(getenv("ND_ATT_QS")) : 0;
+    int qs = qs_env > 0 ? qs_env : 1;
+    if (qs_env <= 0) while (qs < 4 && (long)B * heads * qs < 768 && (NF + qs) / (qs + 1) >= 2) ++qs;
+    if (qs > NF) qs = NF;
+    const int wpq = (NF + qs - 1) / qs;
+    hipLaunchKernelGGL((k_attention_lds<NF>), dim3(B * heads, (NF + wpq - 1) / wpq), dim3(wpq * 64), lds, st, qkv, out, B, N, heads);
     return hipGetLastError();
 }
 
