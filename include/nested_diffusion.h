@@ -162,6 +162,11 @@ int nd_linear(const float *x_dev, const void *w_packed_dev, const float *scale_d
               float *out_dev, int M, int K, int N, int act, int dtype, void *workspace_dev, size_t workspace_bytes,
               void *stream);
 
+/* Launch plan the weight-streaming kernel would use for a Linear of this shape (host-side, no GPU work; tests / tuning):
+ * out6 = {grid.x, grid.y, grid.z (k-slabs), fragment slots per workgroup, k-chunks per slab, threads per workgroup}.
+ * mode 0 fused activation, 1 lin3+lin4 projection, 2 split-K partial sums. */
+int nd_skinny_plan(int K, int N, int M, int n_members, int dtype, int mode, int *out6);
+
 /* Large-M GEMM for the ViT blocks: out[M,N] = act(x[M,K] . W[N,K]^T + bias[n]) (+ residual[M,N]).
  * timm 0.4.12 Attention.qkv / proj, Mlp.fc1 (GELU) / fc2, PatchEmbed.proj as GEMM
  * (call sites classification_train_separately.py:337-340).

@@ -74,6 +74,22 @@ extern "C" int nd_linear(const float* x, const void* wpk, const float* scale, co
     return ND_OK;
 }
 
+// ---- launch-plan introspection (host only; no GPU needed) -------------------------------------
+extern "C" int nd_skinny_plan(int K, int N, int M, int n_members, int dtype, int mode, int* out6) {
+    if (!out6) return nd_set_err(ND_ERR_ARG, "out6 is NULL");
+    if (bad_dtype(dtype) || M < 1 || N < 1 || n_members < 1 || K < kmul(dtype) || (K % kmul(dtype)) || mode < 0 || mode > 2)
+        return nd_set_err(ND_ERR_ARG, "bad shape / dtype / mode");
+    const int half = dtype == ND_DTYPE_F16;
+    const SkinnyLaunch L = mode == 0 ? nd_skinny_launch<0>(K, N, M, n_members, half)
+                         : mode == 1 ? nd_skinny_launch<1>(K, N, M, n_members, half) : nd_skinny_launch<2>(K, N, M, n_members, half);
+    const int nfr = (N + 15) / 16, wpm = (int)L.grid.x / n_members;
+    out6[0] = (int)L.grid.x; out6[1] = (int)L.grid.y; out6[2] = (int)L.grid.z;
+    out6[3] = (nfr + wpm - 1) / wpm;        // fragment slots per workgroup (the kernel's NF)
+    out6[4] = L.cps;                        // k-chunks per slab
+    out6[5] = (int)L.block.x;
+    return ND_OK;
+}
+
 // ---- softmax over the class dim (classification_train_separately.py:755-758) -----------------
 __global__ void k_softmax_rows(const float* __restrict__ x, float* __restrict__ out, int rows, int C) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;

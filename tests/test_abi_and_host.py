@@ -179,3 +179,34 @@ def test_image_folder_pipeline(tmp_path):
     cfg.data.dataset = "MNIST"
     with pytest.raises(NotImplementedError):
         get_test_loader(args, cfg)
+
+
+def test_launch_plans_on_the_host():
+    """The launch-plan helpers are host code: the headline shapes must give at most one 4-wave workgroup per CU, every
+    fragment covered, every k-chunk covered, and the ViT GEMM must ask for a tail workspace only where a partial last round
+    exists."""
+    import ctypes as C
+    from nested_diffusion_amd import _lib
+    lib = _lib.load()
+
+    def plan(K, N, M, nm, dtype=0, mode=0):
+        out = (C.c_int * 6)()
+        assert lib.nd_skinny_plan(K, N, M, nm, dtype, mode, out) == 0, lib.nd_last_error()
+        return list(out)
+
+    for dtype in (0, 1):
+        gx, gy, gz, nf, cps, threads = plan(4096, 4096, 32, 5, dtype, 0)          # lin2 of K = 5 members
+        assert threads == 256 and gy == 1 and gz == 1
+        assert gx <= 256 and gx % 5 == 0 and nf * (gx // 5) >= 256 and nf <= 6      # one workgroup per CU, no member mixing
+        assert cps == 4096 // (32 if dtype else 16)
+    gx, gy, gz, nf, cps, _ = plan(150528, 4096, 32, 1, 0, 2)                        # mapping linear1: split-K fills the CUs
+    assert gx * gy * gz <= 256 and gx * gy * gz >= 192 and nf >= 3 and cps * gz >= 150528 // 16
+    gx, gy, gz, nf, cps, _ = plan(4096, 4096, 640, 5, 0, 0)                         # mc = 20: 64-row groups
+    assert gy == 10 and nf <= 3
+    gx, gy, gz, nf, cps, _ = plan(16, 7, 1, 1, 0, 0)                                # tiny
+    assert (gx, gy, gz, nf) == (1, 1, 1, 1)
+    out = (C.c_int * 6)()
+    assert lib.nd_skinny_plan(48, 16, 1, 1, 1, 0, out) != 0                         # fp16 needs K % 32 == 0
+    assert lib.nd_gemm_workspace_bytes(6272, 768, 768) > 0                          # 588 tiles: 76 left over after 2 rounds
+    assert lib.nd_gemm_workspace_bytes(8192, 4096, 4096) == 0                       # 4096 tiles: whole rounds only
+    assert lib.nd_gemm_workspace_bytes(8, 16, 8) == 0
