@@ -99,3 +99,49 @@ def test_classifier_fp16_vs_oracle_fp16_mode():
     with ref_cpu.fp16_operands():
         ref = ref_cpu.classifier_forward(p, x)
     _close(out, ref, 2e-3)
+
+
+def test_config5_pipeline_fp16_flag_end_to_end():
+    """BASELINE config 5 end to end in shape (ISICSkinCancer temperature, K = 5, T = 1000) with the --fp16 switch of the runner:
+    mapping MLPs, encoder and sampler blocks on fp16 operands (the ViT prefix stays fp32).  Checked against the oracle in its
+    fp16-operand mode (samples relative to the trajectory scale -- T = 1000 amplifies rounding by ~160) and against the
+    fp32 HIP path of the same runner inputs (the mode stays within 5e-2 in class probability on non-saturated rows)."""
+    import argparse
+    from nested_diffusion_amd.mapping import Classifier, GuidingConditioner, VisionTransformer
+    from nested_diffusion_amd.runner import Diffusion
+    ns = argparse.Namespace
+    embed, heads, depth, img, patch, K, B, T, mc, C = 128, 2, 5, 32, 16, 5, 4, 1000, 1, 2
+    D, H, Fd = 3 * img * img, 64, 64
+    vp = ref_cpu.init_vit_params(embed=embed, depth=depth, patch=patch, img=img, seed=13)
+    n_tok = (img // patch) ** 2
+    mlps = [ref_cpu.init_classifier_params(n_tok * embed, widths=(64, 32, 32), seed=120 + i) for i in range(K)]
+    members = [ref_cpu.init_cond_model_params(D, H, Fd, C, T, True, seed=140 + i) for i in range(K)]
+    cfg = ns(data=ns(dataset="ISICSkinCancer", num_classes=C), model=ns(data_dim=D, hidden_dim=H, feature_dim=Fd, arch="linear"),
+             diffusion=ns(timesteps=T, beta_schedule="linear", beta_start=1e-4, beta_end=0.02, aux_cls=ns(arch="sevit"),
+                          trained_aux_cls_ckpt_path="", trained_diffusion_ckpt_path=[[]], include_guidance=True),
+             testing=ns(batch_size=B))
+    g = torch.Generator().manual_seed(19)
+    x = torch.rand(B, 3, img, img, generator=g)
+    noise = torch.randn(K, mc, T, B, C, generator=g)
+    nz = noise.permute(0, 2, 1, 3, 4).reshape(K, T, mc * B, C).cuda()
+    outs = {}
+    for mode in ("f16", "f32"):
+        cond = GuidingConditioner(VisionTransformer(vp, heads), [Classifier(m, dtype=mode) for m in mlps])
+        runner = Diffusion(ns(seed=1, mc_trials=mc, fp16=(mode == "f16")), cfg, device="cuda", conditioner=cond,
+                           noise_estimator_states=members)
+        assert runner.operand_dtype == mode and runner.temperature == 0.3162
+        runner.load_noise_estimators(max_batch=B)
+        assert runner.engine.dtype == (1 if mode == "f16" else 0)
+        outs[mode] = runner.predict_batch(x.cuda(), noise=nz)
+    with ref_cpu.fp16_operands():
+        logits = ref_cpu.compute_guiding_prediction(vp, mlps, x, heads, depth, full_vit=False, share_prefix=True)
+        yhat = [torch.softmax(l, dim=1) for l in logits]
+        alphas, omabs = ref_cpu.schedule_tables("linear", T, 1e-4, 0.02)
+        raw, vote, prob = ref_cpu.ensemble_predict(members, x.flatten(1), yhat, T, alphas, omabs, noise, 0.3162, hoist=True)
+    ref, got = torch.stack(raw), outs["f16"]["samples"].cpu()
+    scale = max(1.0, float(ref.abs().max()))
+    assert (got - ref).abs().max() < 2e-2 * scale, float((got - ref).abs().max() / scale)
+    tame = (ref.abs().amax(dim=(0, 2)) < 50)
+    if tame.any():
+        assert (outs["f16"]["prob"].cpu() - prob)[tame].abs().max() < 2e-2
+        assert (outs["f16"]["prob"] - outs["f32"]["prob"]).cpu()[tame].abs().max() < 5e-2
