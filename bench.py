@@ -42,9 +42,11 @@ def build_runner(args, device):
                           trained_aux_cls_ckpt_path="", trained_diffusion_ckpt_path=[[]], include_guidance=True),
              testing=ns(batch_size=args.batch))
     vit = VisionTransformer(synthetic.vit_state(seed=7, device=device), 12, device)
-    mlps = [Classifier(synthetic.classifier_state(196 * 768, seed=2000 + k, device=device), device) for k in range(K)]
+    mlps = [Classifier(synthetic.classifier_state(196 * 768, seed=2000 + k, device=device), device, dtype=getattr(args, "dtype", "f32"))
+            for k in range(K)]
     states = [synthetic.cond_model_state(D, H, F, C, T, seed=1000 + k, device=device) for k in range(K)]
-    runner = Diffusion(ns(seed=1234, mc_trials=args.mc), cfg, device=device, conditioner=GuidingConditioner(vit, mlps),
+    runner = Diffusion(ns(seed=1234, mc_trials=args.mc, fp16=getattr(args, "dtype", "f32") == "f16"), cfg, device=device,
+                       conditioner=GuidingConditioner(vit, mlps),
                        noise_estimator_states=states)
     runner.load_noise_estimators(max_batch=args.batch, mc_trials=args.mc)
     cpu_member = None
@@ -89,6 +91,9 @@ def main():
     ap.add_argument("--members", type=int, default=5)
     ap.add_argument("--timesteps", type=int, default=100)
     ap.add_argument("--mc", type=int, default=1)
+    ap.add_argument("--dtype", default="f32", choices=("f32", "f16"),
+                    help="operand dtype of the weight-streaming layers; f16 is the secondary fp16-operand mode (BASELINE config 5), "
+                         "never the headline (the reference computes in fp32)")
     ap.add_argument("--no-cpu-baseline", dest="cpu_baseline", action="store_false")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
@@ -102,7 +107,7 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    args.cpu_baseline = args.cpu_baseline and rank == 0 and world == 1
+    args.cpu_baseline = args.cpu_baseline and rank == 0 and world == 1 and args.dtype == "f32"
 
     from nested_diffusion_amd import synthetic
     runner, cfg, cpu_member = build_runner(args, device)
@@ -170,7 +175,8 @@ def main():
     M = B * mc
     # algorithmic bytes of ONE launch of the dominant kernel (k_skinny_fused, lin2 block, all K members in the grid):
     # weights F*F + gain/shift rows 2*F + activations in M*F + out M*F, fp32  (DESIGN.md "roofline accounting")
-    alg_bytes = K * 4.0 * (F * F + 2 * F + 2 * M * F)
+    wb = 4.0 if args.dtype == "f32" else 2.0
+    alg_bytes = K * (wb * F * F + 4.0 * 2 * F + wb * 2 * M * F)
     # The bracketed intervals include the dispatch gap of the graph nodes (~3 us: rocprofv3's begin->end durations of the same
     # kernels are that much shorter, profiles/).  record_node_us is an EMPTY interval (two record nodes back to back, ~6 us),
     # reported for reference; nothing is subtracted, so `achieved` is the conservative figure.
@@ -187,7 +193,9 @@ def main():
     line = {
         "metric": "denoising-steps*images/sec (K=5,T=100,224^2)", "value": value, "unit": "denoising-step*images/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32" if args.dtype == "f32" else "f16 operands / f32 accumulate (secondary mode, not the reference's arithmetic)",
+        "data": "synthetic",
         "config": {"workload": f"K={K} members, T={T} steps, B={B} images/GPU (3x224x224), mc={mc}, D=150528, F=H=4096; "
                                "whole hot path per step: ViT-prefix+mapping MLPs, encoder hoist, K*T reverse steps, aggregation",
                    "global_batch": B * world, "parallelism": f"dp{world} (batch-sharded, all K members per GPU, one all-gather)"},
