@@ -41,7 +41,7 @@ def build_runner(args, device):
              diffusion=ns(timesteps=T, beta_schedule="linear", beta_start=1e-4, beta_end=0.02, aux_cls=ns(arch="sevit"),
                           trained_aux_cls_ckpt_path="", trained_diffusion_ckpt_path=[[]], include_guidance=True),
              testing=ns(batch_size=args.batch))
-    vit = VisionTransformer(synthetic.vit_state(seed=7, device=device), 12, device)
+    vit = VisionTransformer(synthetic.vit_state(seed=7, device=device), 12, device, dtype=getattr(args, "dtype", "f32"))
     mlps = [Classifier(synthetic.classifier_state(196 * 768, seed=2000 + k, device=device), device, dtype=getattr(args, "dtype", "f32"))
             for k in range(K)]
     states = [synthetic.cond_model_state(D, H, F, C, T, seed=1000 + k, device=device) for k in range(K)]

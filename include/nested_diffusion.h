@@ -171,10 +171,12 @@ int nd_skinny_plan(int K, int N, int M, int n_members, int dtype, int mode, int 
  * timm 0.4.12 Attention.qkv / proj, Mlp.fc1 (GELU) / fc2, PatchEmbed.proj as GEMM
  * (call sites classification_train_separately.py:337-340).
  * workspace_dev (>= nd_gemm_workspace_bytes(M, K, N), 16-byte aligned; may be NULL/0): lets the last, partly filled round
- * of output tiles be cut along K across the idle CUs; without it every tile is computed whole (same sums, other order). */
-size_t nd_gemm_workspace_bytes(int M, int K, int N);
-int nd_gemm_bias_act(const float *x_dev, const float *w_dev, const float *bias_dev, const float *residual_dev,
-                     float *out_dev, int M, int K, int N, int act, void *workspace_dev, size_t workspace_bytes,
+ * of output tiles be cut along K across the idle CUs; without it every tile is computed whole (same sums, other order).
+ * dtype ND_DTYPE_F32: w_dev is the fp32 [N,K] weight.  ND_DTYPE_F16 (fp16 mode; K % 32 == 0): w_dev is an fp16 [N,K] copy of it
+ * (row-major, made once by the caller), x is rounded to fp16 on the fly, products exact, fp32 accumulation / epilogue / out. */
+size_t nd_gemm_workspace_bytes(int M, int K, int N, int dtype);
+int nd_gemm_bias_act(const float *x_dev, const void *w_dev, const float *bias_dev, const float *residual_dev,
+                     float *out_dev, int M, int K, int N, int act, int dtype, void *workspace_dev, size_t workspace_bytes,
                      void *stream);
 
 /* nn.LayerNorm(eps) over the last dim: x [rows, dim] -> out.  timm Block.norm1/norm2 (eps 1e-6). */
@@ -182,8 +184,9 @@ int nd_layernorm(const float *x_dev, const float *gamma_dev, const float *beta_d
                  int rows, int dim, float eps, void *stream);
 
 /* timm 0.4.12 Attention core: qkv [B, N, 3, heads, d] (the qkv Linear's output, unpermuted) ->
- * out [B, N, heads*d] = softmax(q k^T * d^-0.5) v, heads concatenated.  d must be 64. */
-int nd_attention(const float *qkv_dev, float *out_dev, int B, int N, int heads, int d, void *stream);
+ * out [B, N, heads*d] = softmax(q k^T * d^-0.5) v, heads concatenated.  d must be 64.
+ * dtype ND_DTYPE_F16 (fp16 mode): q, k, v and the normalised probabilities rounded to fp16, f16 MFMA, fp32 softmax/accumulate/out. */
+int nd_attention(const float *qkv_dev, float *out_dev, int B, int N, int heads, int d, int dtype, void *stream);
 
 /* PatchEmbed im2col: img [B, Cin, Himg, Wimg] NCHW -> cols [B * (Himg/p) * (Wimg/p), Cin*p*p] so that
  * Conv2d(k=p, s=p) becomes nd_gemm_bias_act with the conv weight viewed [embed, Cin*p*p]. */

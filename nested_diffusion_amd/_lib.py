@@ -82,10 +82,10 @@ SIGNATURES = {
     "nd_linear_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "nd_linear": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "nd_skinny_plan": (_i, [_i, _i, _i, _i, _i, _i, C.POINTER(_i)]),
-    "nd_gemm_workspace_bytes": (_sz, [_i, _i, _i]),
-    "nd_gemm_bias_act": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "nd_gemm_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "nd_gemm_bias_act": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "nd_layernorm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
-    "nd_attention": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "nd_attention": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "nd_patchify": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "nd_softmax_rows": (_i, [_vp, _vp, _i, _i, _vp]),
     "nd_aggregate": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),

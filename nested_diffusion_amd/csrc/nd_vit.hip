@@ -163,6 +163,131 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const float* __restrict__ x, co
 }
 
 
+// ---------------------------------------------------------------------------------------------
+// fp16-operand form of the same GEMM (the fp16 mode, BASELINE config 5; not a mode of the reference):
+// x stays fp32 in HBM and is rounded to fp16 on its way into LDS, w is an fp16 [N][K] copy made once at load; products are
+// exact, accumulation / bias / activation / residual fp32, out fp32.  BK = 32 per stage = one v_mfma_f32_16x16x32_f16 per
+// fragment pair; LDS rows are 32 halfs + 8 pad (80 B: the 16 rows of a fragment start at banks 20r mod 64, all distinct,
+// so a lane's 8 halfs k = 8*(l>>4)..+7 are one conflict-free ds_read_b128).  Same tile order, tail split and fixup.
+// ---------------------------------------------------------------------------------------------
+#define GH_K 32
+#define GH_LD 40
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void k_gemm_h(const float* __restrict__ x, const _Float16* __restrict__ w,
+                                                const float* __restrict__ bias, const float* __restrict__ res,
+                                                float* __restrict__ out, int M, int K, int N, int act, int n_full, int split,
+                                                float* __restrict__ part) {
+    constexpr int WM = BM / 2, WN = BN / 2, FM = WM / 16, FN = WN / 16;
+    constexpr int LA = BM * GH_K / 4 / 256;      // float4 (4 fp32) loads per thread for the x tile
+    constexpr int LB = BN * GH_K / 8 / 256;      // 16-byte (8 halfs) loads per thread for the w tile
+    static_assert(LA >= 1 && LB >= 1, "tile too small");
+    __shared__ __attribute__((aligned(16))) _Float16 sA[2][BM][GH_LD];
+    __shared__ __attribute__((aligned(16))) _Float16 sB[2][BN][GH_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int tiles_n = (N + BN - 1) / BN;
+    int bid = blockIdx.x, slab = -1;
+    if (bid < n_full) {
+        const int q = n_full / 8, r = n_full % 8, xcd = bid % 8, loc = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    } else {
+        const int j = bid - n_full;
+        bid = n_full + j / split;
+        slab = j % split;
+    }
+    const int tm = bid / tiles_n, tn = bid % tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float4 ra[LA];
+    f16x8 rb[LB];
+#define GH_GLOAD(k0)                                                                                      \
+    {                                                                                                     \
+        _Pragma("unroll") for (int i = 0; i < LA; ++i) {                                                  \
+            const int e = tid + i * 256, row = e >> 3, kq = (e & 7) * 4;                                  \
+            ra[i] = *reinterpret_cast<const float4*>(x + (size_t)min(m0 + row, M - 1) * K + (k0) + kq);  \
+        }                                                                                                 \
+        _Pragma("unroll") for (int i = 0; i < LB; ++i) {                                                  \
+            const int e = tid + i * 256, row = e >> 2, kq = (e & 3) * 8;                                  \
+            rb[i] = *reinterpret_cast<const f16x8*>(w + (size_t)min(n0 + row, N - 1) * K + (k0) + kq);   \
+        }                                                                                                 \
+    }
+#define GH_SWRITE(buf)                                                                                    \
+    {                                                                                                     \
+        _Pragma("unroll") for (int i = 0; i < LA; ++i) {                                                  \
+            const int e = tid + i * 256, row = e >> 3, kq = (e & 7) * 4;                                  \
+            *reinterpret_cast<f16x4*>(&sA[buf][row][kq]) =                                                \
+                f16x4{(_Float16)ra[i].x, (_Float16)ra[i].y, (_Float16)ra[i].z, (_Float16)ra[i].w};        \
+        }                                                                                                 \
+        _Pragma("unroll") for (int i = 0; i < LB; ++i) {                                                  \
+            const int e = tid + i * 256, row = e >> 2, kq = (e & 3) * 8;                                  \
+            *reinterpret_cast<f16x8*>(&sB[buf][row][kq]) = rb[i];                                         \
+        }                                                                                                 \
+    }
+    const int nkt = K / GH_K;
+    const int ks0 = slab < 0 ? 0 : (int)((long)slab * nkt / split);
+    const int nk = slab < 0 ? nkt : (int)((long)(slab + 1) * nkt / split);
+    GH_GLOAD(ks0 * GH_K)
+    GH_SWRITE(ks0 & 1)
+    __syncthreads();
+    const int lr = lane & 15, lk = 8 * (lane >> 4);
+    for (int ks = ks0; ks < nk; ++ks) {
+        const int buf = ks & 1;
+        GH_GLOAD(min(ks + 1, nk - 1) * GH_K)
+        f16x8 fa[FM], fb[FN];
+#pragma unroll
+        for (int i = 0; i < FM; ++i) fa[i] = *reinterpret_cast<const f16x8*>(&sA[buf][wr * WM + 16 * i + lr][lk]);
+#pragma unroll
+        for (int j = 0; j < FN; ++j) fb[j] = *reinterpret_cast<const f16x8*>(&sB[buf][wc * WN + 16 * j + lr][lk]);
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j], fa[i], acc[i][j], 0, 0, 0);   // D[i=n][j=m]
+        GH_SWRITE(buf ^ 1)
+        __syncthreads();
+    }
+#undef GH_GLOAD
+#undef GH_SWRITE
+    if (slab >= 0) {
+        float* pt = part + ((size_t)(bid - n_full) * split + slab) * (BM * BN);
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+                *reinterpret_cast<float4*>(pt + (wr * WM + 16 * i + (lane & 15)) * BN + wc * WN + 16 * j + 4 * (lane >> 4)) =
+                    make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        const int m = m0 + wr * WM + 16 * i + (lane & 15);
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const int n = n0 + wc * WN + 16 * j + 4 * (lane >> 4);
+            if (m < M && n < N) {
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int nn = min(n + r, N - 1);
+                    float t = acc[i][j][r] + (bias ? bias[nn] : 0.f);
+                    t = nd_act(t, act);
+                    if (res && n + r < N) t += res[(size_t)m * N + n + r];
+                    v[r] = t;
+                }
+                float* p = out + (size_t)m * N + n;
+                if (n + 3 < N && (N & 3) == 0) *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+                else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (n + r < N) p[r] = v[r];
+                }
+            }
+        }
+    }
+}
+
 // Finishes the k-split tiles: out = act(sum_slabs part + bias) + res, slabs added in order (reproducible).
 template <int BM, int BN>
 __global__ __launch_bounds__(256) void k_gemm_fixup(const float* __restrict__ part, const float* __restrict__ bias,
@@ -205,13 +330,13 @@ __global__ __launch_bounds__(256) void k_gemm_fixup(const float* __restrict__ pa
 #define GT_BN 64
 #define GT_CUS 256
 struct GemmPlan { int tiles, n_full, rem, split; size_t ws_bytes; };
-static GemmPlan nd_gemm_plan(int M, int K, int N) {
+static GemmPlan nd_gemm_plan(int M, int K, int N, int bk = GB_K) {
     GemmPlan p{};
     p.tiles = ((M + GT_BM - 1) / GT_BM) * ((N + GT_BN - 1) / GT_BN);
     p.n_full = (p.tiles / GT_CUS) * GT_CUS;
     p.rem = p.tiles - p.n_full;
     p.split = 1;
-    const int nk = K / GB_K;
+    const int nk = K / bk;
     if (p.rem > 0 && (size_t)M * N * K >= ((size_t)1 << 28)) {
         // tail length in tile-times: ceil(rem * s / 256) / s ; take the smallest s that gets within 10 % of the best
         double best = 1e9;
@@ -224,26 +349,34 @@ static GemmPlan nd_gemm_plan(int M, int K, int N) {
     return p;
 }
 
-extern "C" size_t nd_gemm_workspace_bytes(int M, int K, int N) {
-    if (M < 1 || N < 1 || K < 16 || (K % 16)) return 0;
-    return nd_gemm_plan(M, K, N).ws_bytes;
+extern "C" size_t nd_gemm_workspace_bytes(int M, int K, int N, int dtype) {
+    const int km = dtype == ND_DTYPE_F16 ? GH_K : GB_K;
+    if ((dtype != ND_DTYPE_F32 && dtype != ND_DTYPE_F16) || M < 1 || N < 1 || K < km || (K % km)) return 0;
+    return nd_gemm_plan(M, K, N, km).ws_bytes;
 }
 
-extern "C" int nd_gemm_bias_act(const float* x, const float* w, const float* bias, const float* res, float* out, int M, int K,
-                                int N, int act, void* workspace, size_t workspace_bytes, void* stream) {
+extern "C" int nd_gemm_bias_act(const float* x, const void* w, const float* bias, const float* res, float* out, int M, int K,
+                                int N, int act, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
     if (!x || !w || !out) return nd_set_err(ND_ERR_ARG, "NULL tensor");
-    if (M < 1 || N < 1 || K < 16 || (K % 16)) return nd_set_err(ND_ERR_ARG, "need M,N >= 1 and K a positive multiple of 16 (K=%d)", K);
+    if (dtype != ND_DTYPE_F32 && dtype != ND_DTYPE_F16) return nd_set_err(ND_ERR_ARG, "unknown dtype %d", dtype);
+    const int half = dtype == ND_DTYPE_F16, km = half ? GH_K : GB_K;
+    if (M < 1 || N < 1 || K < km || (K % km)) return nd_set_err(ND_ERR_ARG, "need M,N >= 1 and K a positive multiple of %d (K=%d)", km, K);
     if (act < 0 || act > 3) return nd_set_err(ND_ERR_ARG, "unknown activation %d", act);
     hipStream_t st = (hipStream_t)stream;
-    GemmPlan p = nd_gemm_plan(M, K, N);
+    GemmPlan p = nd_gemm_plan(M, K, N, km);
     if (p.split > 1 && (!workspace || workspace_bytes < p.ws_bytes || ((uintptr_t)workspace & 15))) {
         // no (or too small / misaligned) workspace: every tile whole -- same results up to summation order, longer tail
         p.n_full = p.tiles; p.rem = 0; p.split = 1;
     }
     if (p.split == 1) { p.n_full = p.tiles; p.rem = 0; }
     float* part = (float*)workspace;
-    hipLaunchKernelGGL((k_gemm_nt<GT_BM, GT_BN>), dim3((unsigned)(p.n_full + p.rem * p.split)), dim3(256), 0, st, x, w, bias, res, out,
-                       M, K, N, act, p.n_full, p.split, part);
+    const dim3 grid((unsigned)(p.n_full + p.rem * p.split));
+    if (half)
+        hipLaunchKernelGGL((k_gemm_h<GT_BM, GT_BN>), grid, dim3(256), 0, st, x, (const _Float16*)w, bias, res, out, M, K, N, act, p.n_full,
+                           p.split, part);
+    else
+        hipLaunchKernelGGL((k_gemm_nt<GT_BM, GT_BN>), grid, dim3(256), 0, st, x, (const float*)w, bias, res, out, M, K, N, act, p.n_full,
+                           p.split, part);
     HIP_CHECK(hipGetLastError());
     if (p.rem > 0) {
         hipLaunchKernelGGL((k_gemm_fixup<GT_BM, GT_BN>), dim3(GT_BM * GT_BN / 4 / 256, p.rem), dim3(256), 0, st, part, bias, res, out, M, N,
@@ -559,15 +692,150 @@ static hipError_t launch_attention_lds(const float* qkv, float* out, int B, int 
     return hipGetLastError();
 }
 
-extern "C" int nd_attention(const float* qkv, float* out, int B, int N, int heads, int d, void* stream) {
+// fp16-operand form (the fp16 mode; not a mode of the reference): q, k, v are rounded to fp16 as they are staged, both
+// contractions run on v_mfma_f32_16x16x32_f16 with fp32 accumulation, the softmax is fp32 and the normalised probabilities
+// are rounded to fp16 for the second contraction.  K is staged row-major [key][64+8] (a lane's 8 halfs d = 8g..+7 of key
+// l&15: one ds_read_b128), V TRANSPOSED [d][keys+8] so that the 8 k-slots of a lane are two runs of 4 consecutive keys
+// {32F+4g..+3} and {32F+16+4g..+3} -- exactly the keys whose scores that lane already holds in the accumulators of score
+// fragments 2F and 2F+1 (D[i=4g+r][j=query]), so P needs no cross-lane movement.
+#define AH_KLD 72
+template <int NF>
+__global__ __launch_bounds__(NF * 64) void k_attention_h(const float* __restrict__ qkv, float* __restrict__ out, int B, int N,
+                                                          int heads) {
+    constexpr int NFP = (NF + 1) / 2 * 2;                 // score fragments, padded to pairs
+    constexpr int VLD = 16 * NFP + 8;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    _Float16* sK = reinterpret_cast<_Float16*>(smem);     // [16*NFP][AH_KLD]
+    _Float16* sVt = sK + 16 * NFP * AH_KLD;               // [64][VLD]
+    const int tid = threadIdx.x, lane = tid & 63, wave = blockIdx.y * (blockDim.x >> 6) + (tid >> 6);
+    const int bh = blockIdx.x, b = bh / heads, hd = bh % heads;
+    const int Cm = heads * 64;
+    const size_t rs = (size_t)3 * Cm;
+    const float* base = qkv + (size_t)b * N * rs + (size_t)hd * 64;
+    const float* qb = base;
+    const float* kb = base + Cm;
+    const float* vb = base + 2 * Cm;
+    for (int e0 = tid; e0 < 16 * NFP * 16; e0 += 4 * blockDim.x) {     // 16 float4 per 64-float row
+        float4 k4[4], v4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + u * blockDim.x, row = e >> 4, c4 = (e & 15) * 4;
+            k4[u] = make_float4(0.f, 0.f, 0.f, 0.f); v4[u] = k4[u];
+            if (e < 16 * NFP * 16 && row < N) {
+                k4[u] = *reinterpret_cast<const float4*>(kb + (size_t)row * rs + c4);
+                v4[u] = *reinterpret_cast<const float4*>(vb + (size_t)row * rs + c4);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + u * blockDim.x, row = e >> 4, c4 = (e & 15) * 4;
+            if (e < 16 * NFP * 16) {
+                *reinterpret_cast<f16x4*>(sK + row * AH_KLD + c4) = f16x4{(_Float16)k4[u].x, (_Float16)k4[u].y, (_Float16)k4[u].z, (_Float16)k4[u].w};
+                sVt[(c4 + 0) * VLD + row] = (_Float16)v4[u].x;
+                sVt[(c4 + 1) * VLD + row] = (_Float16)v4[u].y;
+                sVt[(c4 + 2) * VLD + row] = (_Float16)v4[u].z;
+                sVt[(c4 + 3) * VLD + row] = (_Float16)v4[u].w;
+            }
+        }
+    }
+    const int g = lane >> 4, li = lane & 15;
+    const int qrow = min(wave * 16 + li, N - 1);
+    f16x8 qh[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const float4 a = *reinterpret_cast<const float4*>(qb + (size_t)qrow * rs + 32 * c + 8 * g);
+        const float4 bq = *reinterpret_cast<const float4*>(qb + (size_t)qrow * rs + 32 * c + 8 * g + 4);
+        qh[c] = f16x8{(_Float16)a.x, (_Float16)a.y, (_Float16)a.z, (_Float16)a.w, (_Float16)bq.x, (_Float16)bq.y, (_Float16)bq.z, (_Float16)bq.w};
+    }
+    __syncthreads();
+    f32x4 s[NFP];
+#pragma unroll
+    for (int f = 0; f < NFP; ++f) {
+        s[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const f16x8 kv = *reinterpret_cast<const f16x8*>(sK + (16 * f + li) * AH_KLD + 32 * c + 8 * g);
+            s[f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kv, qh[c], s[f], 0, 0, 0);      // D[i = key 4g+r][j = query li]
+        }
+    }
+    const float scale = 0.125f;  // 64^-0.5
+    float mx = -INFINITY;
+#pragma unroll
+    for (int f = 0; f < NFP; ++f)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int key = 16 * f + 4 * g + r;
+            const float v = key < N ? s[f][r] * scale : -INFINITY;
+            s[f][r] = v;
+            mx = fmaxf(mx, v);
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int f = 0; f < NFP; ++f)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float p = expf(s[f][r] - mx);
+            s[f][r] = p;
+            sum += p;
+        }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+    f32x4 o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int F2 = 0; F2 < NFP / 2; ++F2) {
+        const f16x8 ph = {(_Float16)(s[2 * F2][0] * inv), (_Float16)(s[2 * F2][1] * inv), (_Float16)(s[2 * F2][2] * inv), (_Float16)(s[2 * F2][3] * inv),
+                          (_Float16)(s[2 * F2 + 1][0] * inv), (_Float16)(s[2 * F2 + 1][1] * inv), (_Float16)(s[2 * F2 + 1][2] * inv),
+                          (_Float16)(s[2 * F2 + 1][3] * inv)};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const _Float16* vp = sVt + (16 * e + li) * VLD + 32 * F2 + 4 * g;
+            const f16x4 v0 = *reinterpret_cast<const f16x4*>(vp), v1 = *reinterpret_cast<const f16x4*>(vp + 16);
+            const f16x8 vh = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            o[e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, ph, o[e], 0, 0, 0);          // D[i = d 16e+4g+r][j = query li]
+        }
+    }
+    const int qo = wave * 16 + li;
+    if (qo < N) {
+        float* op = out + ((size_t)b * N + qo) * Cm + (size_t)hd * 64 + 4 * g;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) *reinterpret_cast<float4*>(op + 16 * e) = make_float4(o[e][0], o[e][1], o[e][2], o[e][3]);
+    }
+}
+
+template <int NF>
+static hipError_t launch_attention_h(const float* qkv, float* out, int B, int N, int heads, hipStream_t st) {
+    constexpr int NFP = (NF + 1) / 2 * 2;
+    const size_t lds = ((size_t)16 * NFP * AH_KLD + (size_t)64 * (16 * NFP + 8)) * sizeof(_Float16);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_attention_h<NF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    int qs = 1;
+    while (qs < 4 && (long)B * heads * qs < 768 && (NF + qs) / (qs + 1) >= 2) ++qs;
+    if (qs > NF) qs = NF;
+    const int wpq = (NF + qs - 1) / qs;
+    hipLaunchKernelGGL((k_attention_h<NF>), dim3(B * heads, (NF + wpq - 1) / wpq), dim3(wpq * 64), lds, st, qkv, out, B, N, heads);
+    return hipGetLastError();
+}
+
+extern "C" int nd_attention(const float* qkv, float* out, int B, int N, int heads, int d, int dtype, void* stream) {
     if (!qkv || !out) return nd_set_err(ND_ERR_ARG, "NULL tensor");
     if (d != 64) return nd_set_err(ND_ERR_ARG, "head dim must be 64 (got %d)", d);
+    if (dtype != ND_DTYPE_F32 && dtype != ND_DTYPE_F16) return nd_set_err(ND_ERR_ARG, "unknown dtype %d", dtype);
     if (B < 1 || heads < 1 || N < 1 || N > 16 * AT_MAXF) return nd_set_err(ND_ERR_ARG, "need 1 <= N <= %d", 16 * AT_MAXF);
     hipStream_t st = (hipStream_t)stream;
     const int nf = (N + 15) / 16;
     static const int form = getenv("ND_ATT_FORM") ? atoi(getenv("ND_ATT_FORM")) : 1;   // 1 = K/V in LDS, 0 = K/V from L2 per wave
     const dim3 grid((nf + 3) / 4, B * heads), block(256);
-#define AT_CASE(NFV) case NFV: if (form == 1) HIP_CHECK((launch_attention_lds<NFV>(qkv, out, B, N, heads, st))); \
+#define AT_CASE(NFV) case NFV: if (dtype == ND_DTYPE_F16) HIP_CHECK((launch_attention_h<NFV>(qkv, out, B, N, heads, st)));  \
+                               else if (form == 1) HIP_CHECK((launch_attention_lds<NFV>(qkv, out, B, N, heads, st))); \
                                else hipLaunchKernelGGL((k_attention_d64<NFV, 1, 2>), grid, block, 0, st, qkv, out, B, N, heads); break;
     switch (nf) {
         AT_CASE(1) AT_CASE(2) AT_CASE(3) AT_CASE(4) AT_CASE(5) AT_CASE(6) AT_CASE(7) AT_CASE(8)

@@ -16,7 +16,7 @@ from typing import Dict, List, Optional, Sequence
 
 import torch
 
-from . import ops
+from . import _lib, ops
 
 LN_EPS = 1e-6  # timm 0.4.12: norm_layer = partial(nn.LayerNorm, eps=1e-6)
 
@@ -54,13 +54,21 @@ class Classifier:
 class VisionTransformer:
     """The subset of timm 0.4.12 VisionTransformer the path touches, over a timm state_dict."""
 
-    def __init__(self, state_dict: Dict[str, torch.Tensor], num_heads: int = 12, device="cuda"):
+    def __init__(self, state_dict: Dict[str, torch.Tensor], num_heads: int = 12, device="cuda", dtype="f32"):
+        """dtype 'f16' (fp16 mode, not a reference mode): the Linear / patch-embedding weights are held in fp16 and the GEMMs and
+        the attention contractions run on fp16 operands (fp32 accumulation, LayerNorm, softmax, residual stream)."""
         self.device = torch.device(device)
+        self.dtype = "f16" if _lib.dtype_code(dtype) == _lib.ND_DTYPE_F16 else "f32"
         self.p = {k: v.detach().to(self.device, torch.float32).contiguous() for k, v in state_dict.items()
                   if torch.is_tensor(v) and v.is_floating_point()}
         w = self.p["patch_embed.proj.weight"]
         self.embed_dim, self.in_chans, self.patch = w.shape[0], w.shape[1], w.shape[-1]
         self.pe_w = w.reshape(self.embed_dim, -1).contiguous()
+        if self.dtype == "f16":
+            self.pe_w = self.pe_w.half()
+            for k in list(self.p):
+                if k.startswith("blocks.") and k.endswith(("attn.qkv.weight", "attn.proj.weight", "mlp.fc1.weight", "mlp.fc2.weight")):
+                    self.p[k] = self.p[k].half()
         self.num_heads = num_heads
         self.depth = 1 + max(int(k.split(".")[1]) for k in self.p if k.startswith("blocks."))
         if self.embed_dim // num_heads != 64:
@@ -77,7 +85,7 @@ class VisionTransformer:
         N = tok.shape[0] // B
         h = ops.layernorm(tok, p[pre + "norm1.weight"], p[pre + "norm1.bias"], LN_EPS)
         qkv = ops.gemm_bias_act(h, p[pre + "attn.qkv.weight"], p[pre + "attn.qkv.bias"])
-        a = ops.attention(qkv, B, N, self.num_heads)
+        a = ops.attention(qkv, B, N, self.num_heads, self.dtype)
         tok = ops.gemm_bias_act(a, p[pre + "attn.proj.weight"], p[pre + "attn.proj.bias"], residual=tok)
         h = ops.layernorm(tok, p[pre + "norm2.weight"], p[pre + "norm2.bias"], LN_EPS)
         h = ops.gemm_bias_act(h, p[pre + "mlp.fc1.weight"], p[pre + "mlp.fc1.bias"], act="gelu")
@@ -171,4 +179,4 @@ def load_conditioner(trained_path: str, dataset: str, device="cuda", num_heads: 
     vit_sd = load_pickled(os.path.join(trained_path, f"vit_base_patch16_224_{dataset}.pth"))
     mlp_dir = os.path.join(trained_path, "MLPs")
     mlps = [Classifier(load_pickled(os.path.join(mlp_dir, f)), device, dtype) for f in sorted(os.listdir(mlp_dir))]
-    return GuidingConditioner(VisionTransformer(vit_sd, num_heads, device), mlps)
+    return GuidingConditioner(VisionTransformer(vit_sd, num_heads, device, dtype), mlps)

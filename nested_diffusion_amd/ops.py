@@ -81,9 +81,16 @@ def linear(x: torch.Tensor, weight, bias: Optional[torch.Tensor] = None, act=Non
 
 def gemm_bias_act(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, act=None,
                   residual: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """act(x @ weight.T + bias) + residual for large row counts (ViT token matrices)."""
+    """act(x @ weight.T + bias) + residual for large row counts (ViT token matrices).
+    A float16 `weight` selects the fp16-operand kernel (x rounded to fp16 on the fly, fp32 accumulate / out; K % 32 == 0)."""
     lib = _lib.load()
-    x, weight = _f32(x, "x"), _f32(weight, "weight")
+    x = _f32(x, "x")
+    if not weight.is_cuda:
+        raise _lib.NdError("weight must be a GPU tensor (no CPU fallback)")
+    if weight.dtype == torch.float16:
+        weight, dt = weight.contiguous(), _lib.ND_DTYPE_F16
+    else:
+        weight, dt = _f32(weight, "weight"), _lib.ND_DTYPE_F32
     M, K = x.shape
     N = weight.shape[0]
     if weight.shape[1] != K:
@@ -93,9 +100,9 @@ def gemm_bias_act(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Te
     if residual is not None and tuple(residual.shape) != (M, N):
         raise ValueError("residual must be [M, N]")
     out = torch.empty(M, N, dtype=torch.float32, device=x.device)
-    nbytes = lib.nd_gemm_workspace_bytes(M, K, N)
+    nbytes = lib.nd_gemm_workspace_bytes(M, K, N, dt)
     ws = _workspace(nbytes, x.device) if nbytes else None
-    check(lib.nd_gemm_bias_act(ptr(x), ptr(weight), ptr(bias), ptr(residual), ptr(out), M, K, N, ACT[act], ptr(ws),
+    check(lib.nd_gemm_bias_act(ptr(x), ptr(weight), ptr(bias), ptr(residual), ptr(out), M, K, N, ACT[act], dt, ptr(ws),
                                ws.numel() if ws is not None else 0, _stream(x)), "nd_gemm_bias_act")
     return out
 
@@ -111,15 +118,15 @@ def layernorm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: fl
     return out
 
 
-def attention(qkv: torch.Tensor, B: int, N: int, heads: int) -> torch.Tensor:
-    """qkv: [B*N, 3*heads*64] (output of the qkv Linear) -> [B*N, heads*64]."""
+def attention(qkv: torch.Tensor, B: int, N: int, heads: int, dtype="f32") -> torch.Tensor:
+    """qkv: [B*N, 3*heads*64] (output of the qkv Linear) -> [B*N, heads*64].  dtype 'f16': fp16-operand contractions."""
     lib = _lib.load()
     qkv = _f32(qkv, "qkv")
     d = qkv.shape[-1] // (3 * heads)
     if qkv.numel() != B * N * 3 * heads * d:
         raise ValueError("qkv has the wrong number of elements")
     out = torch.empty(B * N, heads * d, dtype=torch.float32, device=qkv.device)
-    check(lib.nd_attention(ptr(qkv), ptr(out), B, N, heads, d, _stream(qkv)), "nd_attention")
+    check(lib.nd_attention(ptr(qkv), ptr(out), B, N, heads, d, _lib.dtype_code(dtype), _stream(qkv)), "nd_attention")
     return out
 
 

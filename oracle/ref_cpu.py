@@ -77,16 +77,30 @@ def schedule_tables(schedule: str, num_timesteps: int, start: float, end: float)
 # accumulation; everything else (BatchNorm, gains, softplus, lin1, lin4, the sampler state) stays fp32.
 # ----------------------------------------------------------------------------
 _FP16_OPERANDS = False
+_FP16_VIT = False
 
 
 @contextlib.contextmanager
-def fp16_operands(enable: bool = True):
-    global _FP16_OPERANDS
-    prev, _FP16_OPERANDS = _FP16_OPERANDS, bool(enable)
+def fp16_operands(enable: bool = True, vit: bool = False):
+    """vit=True additionally models the build's fp16 ViT prefix: patch embedding and the four Linear layers of a block on
+    fp16-rounded operands, attention with q, k, v and the normalised probabilities rounded to fp16 (fp32 softmax)."""
+    global _FP16_OPERANDS, _FP16_VIT
+    prev = (_FP16_OPERANDS, _FP16_VIT)
+    _FP16_OPERANDS, _FP16_VIT = bool(enable), bool(enable and vit)
     try:
         yield
     finally:
-        _FP16_OPERANDS = prev
+        _FP16_OPERANDS, _FP16_VIT = prev
+
+
+def _vit_linear(x: Tensor, w: Tensor, b: Optional[Tensor]) -> Tensor:
+    if _FP16_VIT:
+        x, w = x.half().float(), w.half().float()
+    return F.linear(x, w, b)
+
+
+def _h(x: Tensor) -> Tensor:
+    return x.half().float() if _FP16_VIT else x
 
 
 def _big_linear(x: Tensor, w: Tensor, b: Optional[Tensor]) -> Tensor:
@@ -277,7 +291,7 @@ def vit_patch_embed(vp: Dict[str, Tensor], x: Tensor) -> Tensor:
     (classification_train_separately.py:337-338)."""
     w = vp["patch_embed.proj.weight"]
     ps = w.shape[-1]
-    return F.conv2d(x, w, vp["patch_embed.proj.bias"], stride=ps).flatten(2).transpose(1, 2)
+    return F.conv2d(_h(x), _h(w), vp["patch_embed.proj.bias"], stride=ps).flatten(2).transpose(1, 2)
 
 
 def vit_block(vp: Dict[str, Tensor], i: int, x: Tensor, num_heads: int) -> Tensor:
@@ -287,17 +301,17 @@ def vit_block(vp: Dict[str, Tensor], i: int, x: Tensor, num_heads: int) -> Tenso
     B, N, C = x.shape
     d = C // num_heads
     h = F.layer_norm(x, (C,), vp[pre + "norm1.weight"], vp[pre + "norm1.bias"], LN_EPS)
-    qkv = F.linear(h, vp[pre + "attn.qkv.weight"], vp[pre + "attn.qkv.bias"])
+    qkv = _vit_linear(h, vp[pre + "attn.qkv.weight"], vp[pre + "attn.qkv.bias"])
     qkv = qkv.reshape(B, N, 3, num_heads, d).permute(2, 0, 3, 1, 4)
-    q, k, v = qkv[0], qkv[1], qkv[2]
+    q, k, v = _h(qkv[0]), _h(qkv[1]), _h(qkv[2])
     attn = (q @ k.transpose(-2, -1)) * (d ** -0.5)
     attn = attn.softmax(dim=-1)
-    h = (attn @ v).transpose(1, 2).reshape(B, N, C)
-    h = F.linear(h, vp[pre + "attn.proj.weight"], vp[pre + "attn.proj.bias"])
+    h = (_h(attn) @ v).transpose(1, 2).reshape(B, N, C)
+    h = _vit_linear(h, vp[pre + "attn.proj.weight"], vp[pre + "attn.proj.bias"])
     x = x + h
     h = F.layer_norm(x, (C,), vp[pre + "norm2.weight"], vp[pre + "norm2.bias"], LN_EPS)
-    h = F.gelu(F.linear(h, vp[pre + "mlp.fc1.weight"], vp[pre + "mlp.fc1.bias"]))
-    h = F.linear(h, vp[pre + "mlp.fc2.weight"], vp[pre + "mlp.fc2.bias"])
+    h = F.gelu(_vit_linear(h, vp[pre + "mlp.fc1.weight"], vp[pre + "mlp.fc1.bias"]))
+    h = _vit_linear(h, vp[pre + "mlp.fc2.weight"], vp[pre + "mlp.fc2.bias"])
     return x + h
 
 

@@ -207,6 +207,7 @@ def test_launch_plans_on_the_host():
     assert (gx, gy, gz, nf) == (1, 1, 1, 1)
     out = (C.c_int * 6)()
     assert lib.nd_skinny_plan(48, 16, 1, 1, 1, 0, out) != 0                         # fp16 needs K % 32 == 0
-    assert lib.nd_gemm_workspace_bytes(6272, 768, 768) > 0                          # 588 tiles: 76 left over after 2 rounds
-    assert lib.nd_gemm_workspace_bytes(8192, 4096, 4096) == 0                       # 4096 tiles: whole rounds only
-    assert lib.nd_gemm_workspace_bytes(8, 16, 8) == 0
+    assert lib.nd_gemm_workspace_bytes(6272, 768, 768, 0) > 0                          # 588 tiles: 76 left over after 2 rounds
+    assert lib.nd_gemm_workspace_bytes(8192, 4096, 4096, 0) == 0                       # 4096 tiles: whole rounds only
+    assert lib.nd_gemm_workspace_bytes(8, 16, 8, 0) == 0
+    assert lib.nd_gemm_workspace_bytes(6272, 768, 768, 1) > 0 and lib.nd_gemm_workspace_bytes(6272, 48, 768, 1) == 0   # fp16: K % 32

@@ -103,7 +103,7 @@ def test_classifier_fp16_vs_oracle_fp16_mode():
 
 def test_config5_pipeline_fp16_flag_end_to_end():
     """BASELINE config 5 end to end in shape (ISICSkinCancer temperature, K = 5, T = 1000) with the --fp16 switch of the runner:
-    mapping MLPs, encoder and sampler blocks on fp16 operands (the ViT prefix stays fp32).  Checked against the oracle in its
+    ViT prefix (GEMMs + MFMA attention), mapping MLPs, encoder and sampler blocks on fp16 operands.  Checked against the oracle in its
     fp16-operand mode (samples relative to the trajectory scale -- T = 1000 amplifies rounding by ~160) and against the
     fp32 HIP path of the same runner inputs (the mode stays within 5e-2 in class probability on non-saturated rows)."""
     import argparse
@@ -126,14 +126,14 @@ def test_config5_pipeline_fp16_flag_end_to_end():
     nz = noise.permute(0, 2, 1, 3, 4).reshape(K, T, mc * B, C).cuda()
     outs = {}
     for mode in ("f16", "f32"):
-        cond = GuidingConditioner(VisionTransformer(vp, heads), [Classifier(m, dtype=mode) for m in mlps])
+        cond = GuidingConditioner(VisionTransformer(vp, heads, dtype=mode), [Classifier(m, dtype=mode) for m in mlps])
         runner = Diffusion(ns(seed=1, mc_trials=mc, fp16=(mode == "f16")), cfg, device="cuda", conditioner=cond,
                            noise_estimator_states=members)
         assert runner.operand_dtype == mode and runner.temperature == 0.3162
         runner.load_noise_estimators(max_batch=B)
         assert runner.engine.dtype == (1 if mode == "f16" else 0)
         outs[mode] = runner.predict_batch(x.cuda(), noise=nz)
-    with ref_cpu.fp16_operands():
+    with ref_cpu.fp16_operands(vit=True):
         logits = ref_cpu.compute_guiding_prediction(vp, mlps, x, heads, depth, full_vit=False, share_prefix=True)
         yhat = [torch.softmax(l, dim=1) for l in logits]
         alphas, omabs = ref_cpu.schedule_tables("linear", T, 1e-4, 0.02)
@@ -145,3 +145,61 @@ def test_config5_pipeline_fp16_flag_end_to_end():
     if tame.any():
         assert (outs["f16"]["prob"].cpu() - prob)[tame].abs().max() < 2e-2
         assert (outs["f16"]["prob"] - outs["f32"]["prob"]).cpu()[tame].abs().max() < 5e-2
+
+
+@pytest.mark.parametrize("M,K,N,act,res", [(6272, 768, 768, None, True), (392, 768, 2304, None, False), (6250, 768, 3070, "gelu", True),
+                                           (6272, 3072, 768, None, True), (200, 64, 256, "gelu", False), (130, 32, 70, None, True),
+                                           (1, 32, 1, "relu", False)])
+def test_gemm_fp16_operands(M, K, N, act, res):
+    """nd_gemm_bias_act with an fp16 weight == the fp32 GEMM on fp16-rounded operands (exact products, fp32 accumulation):
+    2e-5 relative, as for the fp32 kernel."""
+    from nested_diffusion_amd import ops
+    g = torch.Generator().manual_seed(M + N)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    r = torch.randn(M, N, generator=g) if res else None
+    out = ops.gemm_bias_act(x.cuda(), w.half().cuda(), b.cuda(), act=act, residual=r.cuda() if res else None)
+    ref = (x.half().double() @ w.half().double().T).float() + b
+    ref = {None: lambda v: v, "relu": F.relu, "gelu": F.gelu}[act](ref)
+    if res:
+        ref = ref + r
+    _close(out, ref, 2e-5)
+
+
+@pytest.mark.parametrize("B,N,heads", [(2, 196, 12), (1, 197, 12), (3, 16, 2), (2, 5, 1), (1, 256, 3), (2, 50, 4), (32, 196, 12)])
+def test_attention_fp16_operands(B, N, heads):
+    """nd_attention dtype f16 against torch on fp16-rounded q, k, v and fp16-rounded probabilities (fp32 softmax and sums).
+    A probability can land on the neighbouring fp16 value (the kernel's fp32 softmax differs from torch's in the last bits):
+    5e-4 relative (fp32 kernel: 2e-5)."""
+    from nested_diffusion_amd import ops
+    d = 64
+    g = torch.Generator().manual_seed(N)
+    qkv = torch.randn(B * N, 3 * heads * d, generator=g)
+    out = ops.attention(qkv.cuda(), B, N, heads, dtype="f16")
+    t = qkv.half().double().reshape(B, N, 3, heads, d).permute(2, 0, 3, 1, 4)
+    attn = ((t[0] @ t[1].transpose(-2, -1)) * d ** -0.5).float().softmax(-1)
+    ref = (attn.half().double() @ t[2]).transpose(1, 2).reshape(B * N, heads * d).float()
+    _close(out, ref, 5e-4)
+
+
+def test_vit_prefix_fp16_vs_oracle_fp16_vit_mode():
+    """The whole mapping network in fp16 mode (ViT GEMMs + attention + MLPs) against the oracle with fp16_operands(vit=True),
+    and against the fp32 HIP path: logits within 2e-2 of the fp16 oracle / 5e-2 of fp32 at test dims."""
+    from nested_diffusion_amd.mapping import Classifier, GuidingConditioner, VisionTransformer
+    embed, heads, depth, img, patch, K, B = 128, 2, 5, 32, 16, 5, 3
+    vp = ref_cpu.init_vit_params(embed=embed, depth=depth, patch=patch, img=img, seed=5)
+    n_tok = (img // patch) ** 2
+    mlps = [ref_cpu.init_classifier_params(n_tok * embed, widths=(64, 32, 32), seed=60 + i) for i in range(K)]
+    x = torch.rand(B, 3, img, img, generator=torch.Generator().manual_seed(2))
+    c16 = GuidingConditioner(VisionTransformer(vp, heads, dtype="f16"), [Classifier(m, dtype="f16") for m in mlps])
+    c32 = GuidingConditioner(VisionTransformer(vp, heads), [Classifier(m) for m in mlps])
+    l16 = [t.cpu() for t in c16.compute_guiding_prediction(x.cuda(), include_full_vit=False)]
+    l32 = [t.cpu() for t in c32.compute_guiding_prediction(x.cuda(), include_full_vit=False)]
+    with ref_cpu.fp16_operands(vit=True):
+        ref = ref_cpu.compute_guiding_prediction(vp, mlps, x, heads, depth, full_vit=False, share_prefix=True)
+    for k in range(K):
+        scale = max(1.0, float(ref[k].abs().max()))
+        assert (l16[k] - ref[k]).abs().max() < 2e-2 * scale
+        assert (l16[k] - l32[k]).abs().max() < 5e-2 * scale
+        assert (l16[k] - l32[k]).abs().max() > 0            # the mode is really on

@@ -72,7 +72,7 @@ def test_gemm_without_workspace_matches_split_path():
     from nested_diffusion_amd import _lib, ops
     lib = _lib.load()
     M, K, N = 6272, 768, 768
-    assert lib.nd_gemm_workspace_bytes(M, K, N) > 0                     # this shape takes the k-split tail
+    assert lib.nd_gemm_workspace_bytes(M, K, N, 0) > 0                     # this shape takes the k-split tail
     g = torch.Generator().manual_seed(5)
     x = torch.randn(M, K, generator=g).cuda()
     w = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
@@ -80,7 +80,7 @@ def test_gemm_without_workspace_matches_split_path():
     a = ops.gemm_bias_act(x, w, b)
     out = torch.empty(M, N, device="cuda")
     st = torch.cuda.current_stream().cuda_stream
-    _lib.check(lib.nd_gemm_bias_act(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), None, _lib.ptr(out), M, K, N, 0, None, 0, st), "gemm")
+    _lib.check(lib.nd_gemm_bias_act(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), None, _lib.ptr(out), M, K, N, 0, 0, None, 0, st), "gemm")
     torch.cuda.synchronize()
     assert (a - out).abs().max().item() < 2e-5
     assert torch.equal(a, ops.gemm_bias_act(x, w, b))                    # reproducible run to run
