@@ -279,16 +279,29 @@ __global__ __launch_bounds__(WAVES * 64) void k_skinny(SkinnyDesc d0, const Skin
         auto G = [&](int i) { return min(wave + i * WAVES, glast); };      // group of this wave's i-th turn (clamped)
         int i = 0;
         if (ngw > 0) LD(wA, xA, G(0));
+        // Steady state.  The next stage's loads are either issued in a block before the current stage's MFMAs, or spread
+        // through them (one load per MR MFMAs: the matrix pipe never waits for the ~150 cycles of load issue).  Measured
+        // (K=5, M=32, in the sampler graph): spread is 3 us faster for MODE 0 and 3 us SLOWER for MODE 1 -- same loop, the
+        // compiler's schedule around it differs -- so it is chosen per mode.
+        constexpr bool SPREAD = MODE != 1;
+        constexpr int NL = U * (NFA + MT), NM = U * (H ? 1 : 4) * NFA * MT, MR = NM / NL > 0 ? NM / NL : 1;
+#define ND_MIX()                                                                                     \
+        _Pragma("unroll") for (int q_ = 0; q_ < NL; ++q_) {                                          \
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                       \
+            __builtin_amdgcn_sched_group_barrier(0x008, MR, 0);                                      \
+        }                                                                                            \
+        __builtin_amdgcn_sched_barrier(0);
         for (; i + 1 < ngw; i += 2) {
             LD(wB, xB, G(i + 1));
-            __builtin_amdgcn_sched_barrier(0);
+            if (!SPREAD) __builtin_amdgcn_sched_barrier(0);
             MMA(wA, xA);
-            __builtin_amdgcn_sched_barrier(0);
+            if (SPREAD) { ND_MIX() } else __builtin_amdgcn_sched_barrier(0);
             LD(wA, xA, G(i + 2));          // i + 2 == ngw on the last pair of an even count: re-reads a valid group, unused
-            __builtin_amdgcn_sched_barrier(0);
+            if (!SPREAD) __builtin_amdgcn_sched_barrier(0);
             MMA(wB, xB);
-            __builtin_amdgcn_sched_barrier(0);
+            if (SPREAD) { ND_MIX() } else __builtin_amdgcn_sched_barrier(0);
         }
+#undef ND_MIX
         if (i < ngw) MMA(wA, xA);
     };
     if (nact == NF) {

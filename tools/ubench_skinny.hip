@@ -873,7 +873,7 @@ int main(int argc, char** argv) {
     if (argc > 3 && argv[3][0] == 'T') {      // per-workgroup timing of the library kernel (MODE 0)
         long long* dbg; CK(hipMalloc(&dbg, 8192 * 3 * 8)); CK(hipMemset(dbg, 0, 8192 * 3 * 8));
         CK(hipMemcpyToSymbol(HIP_SYMBOL(nd_dbg_times), &dbg, sizeof dbg));
-        for (int rep = 0; rep < 3; ++rep) launch_lib<0, 0>(p, G, st);
+        for (int rep = 0; rep < 3; ++rep) { if (argv[3][1] == '1') launch_lib<1, 1>(p, G, st); else launch_lib<0, 0>(p, G, st); }
         CK(hipStreamSynchronize(st));
         std::vector<long long> h(8192 * 3);
         CK(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
@@ -884,6 +884,16 @@ int main(int argc, char** argv) {
         for (unsigned b = 0; b < L.grid.x; ++b) tot.push_back({(h[b * 3 + 2] - tmin) / 100.0, b});
         std::sort(tot.begin(), tot.end());
         auto pr = [&](unsigned b) { printf("  wg %4u: start %6.2f  loop-end %6.2f  red-written %6.2f  activated %6.2f  end %6.2f\n", b, (h[b * 3] - tmin) / 100.0, (h[b * 3 + 1] - tmin) / 100.0, (h[(4096 + b) * 3] - tmin) / 100.0, (h[(4096 + b) * 3 + 1] - tmin) / 100.0, (h[b * 3 + 2] - tmin) / 100.0); };
+        {   // loop-end by XCD (blockIdx % 8) and by member
+            double sx[8] = {0}, sm[16] = {0}; int nx[8] = {0}, nmm[16] = {0};
+            const unsigned wpm = L.grid.x / G;
+            for (unsigned b = 0; b < L.grid.x; ++b) {
+                const double le = (h[b * 3 + 1] - tmin) / 100.0;
+                sx[b % 8] += le; nx[b % 8]++; sm[b / wpm] += le; nmm[b / wpm]++;
+            }
+            printf("mean loop-end by XCD:"); for (int i = 0; i < 8; ++i) printf(" %.1f", sx[i] / nx[i]); printf("\n");
+            printf("mean loop-end by member:"); for (int i = 0; i < G; ++i) printf(" %.1f", sm[i] / nmm[i]); printf("\n");
+        }
         printf("earliest finishers:\n"); for (int i = 0; i < 4; ++i) pr(tot[i].second);
         printf("median:\n"); pr(tot[tot.size() / 2].second);
         printf("latest finishers:\n"); for (size_t i = tot.size() - 8; i < tot.size(); ++i) pr(tot[i].second);
