@@ -150,6 +150,12 @@ __device__ __forceinline__ float4 nd_ld16(const float* p) {
 __device__ long long* nd_dbg_times = nullptr;   // tools/ubench_skinny.hip: per-workgroup (start, loop end, end) clocks
 #endif
 
+// scalar load from GLOBAL memory through a pointer the compiler only knows as generic (it came out of a descriptor table):
+// a pending flat_load cannot be counted (it may be LDS or global), so every later wait would become vmcnt(0) lgkmcnt(0)
+__device__ __forceinline__ float nd_ldg(const float* p) {
+    return *(const __attribute__((address_space(1))) float*)p;
+}
+
 // One skinny Linear on packed operands, for `nm` members that share the layer shape (K, N):
 //   MODE 0: out[m,n] = act(scale[t,n] * sum_k x[m,k] w[n,k] + shift[t,n])
 //   MODE 1: that value is not stored; its projection onto C rows is: part[m,c,tile] = sum_{n in tile} pw[c,n]*v
@@ -219,17 +225,18 @@ __global__ __launch_bounds__(WAVES * 64) void k_skinny(SkinnyDesc d0, const Skin
         // thread tid < NF*16 owns column (f = tid/16, nl = tid%16); thread tid < NF*C*16 owns lin4 entry (f, c, nl)
         if (tid < NF * 16) {
             const int n = min(min(fi0 + (tid >> 4), nfr - 1) * 16 + (tid & 15), N - 1);
-            if (d.scale) r_sc = d.scale[(size_t)t * N + n];
-            if (d.shift) r_sh = d.shift[(size_t)t * N + n];
+            if (d.scale) r_sc = nd_ldg(d.scale + (size_t)t * N + n);
+            if (d.shift) r_sh = nd_ldg(d.shift + (size_t)t * N + n);
         }
+        // lin4 rows: one entry per thread when they fit (NF*C*16 <= threads), requested now and parked after the main loop;
+        // otherwise (large C) fetched after the loop.  No load inside a loop of unknown trip count here: with one pending the
+        // compiler can no longer count outstanding loads and degrades every wait of the main loop to vmcnt(0).
+        // (an unconditional load on a clamped address, in the global address space: see nd_ldg)
         if (MODE == 1) {
-            const bool one_pass = NF * eC * 16 <= WAVES * 64;          // one entry per thread: keep it in a register for now
-            for (int e = tid; e < NF * eC * 16; e += WAVES * 64) {
-                const int f = e / (eC * 16), c = (e / 16) % eC, nl = e & 15;
-                const int n = min(fi0 + f, nfr - 1) * 16 + nl;
-                r_pw = n < N ? d.pw[(size_t)c * N + n] : 0.f;
-                if (!one_pass) pws[f][c][nl] = r_pw;                    // more entries than threads (large C): store at once
-            }
+            const int e = min(tid, NF * eC * 16 - 1);
+            const int f = e / (eC * 16), c = (e / 16) % eC, nl = e & 15;
+            const int n = min(min(fi0 + f, nfr - 1) * 16 + nl, N - 1);
+            r_pw = nd_ldg(d.pw + (size_t)c * N + n);
         }
     }
 
@@ -283,8 +290,12 @@ __global__ __launch_bounds__(WAVES * 64) void k_skinny(SkinnyDesc d0, const Skin
         // through them (one load per MR MFMAs: the matrix pipe never waits for the ~150 cycles of load issue).  Measured
         // (K=5, M=32, in the sampler graph): spread is 3 us faster for MODE 0 and 3 us SLOWER for MODE 1 -- same loop, the
         // compiler's schedule around it differs -- so it is chosen per mode.
-        constexpr bool SPREAD = MODE != 1;
-        constexpr int NL = U * (NFA + MT), NM = U * (H ? 1 : 4) * NFA * MT, MR = NM / NL > 0 ? NM / NL : 1;
+#ifndef ND_MR1
+#define ND_MR1 0
+#endif
+        constexpr bool SPREAD = ND_MR1 >= 0;
+        constexpr int NL = U * (NFA + MT), NM = U * (H ? 1 : 4) * NFA * MT;
+        constexpr int MR = (MODE == 1 && ND_MR1 > 0) ? ND_MR1 : (NM / NL > 0 ? NM / NL : 1);
 #define ND_MIX()                                                                                     \
         _Pragma("unroll") for (int q_ = 0; q_ < NL; ++q_) {                                          \
             __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                       \
@@ -335,7 +346,20 @@ __global__ __launch_bounds__(WAVES * 64) void k_skinny(SkinnyDesc d0, const Skin
     // park the epilogue operands (in registers since the prologue) in LDS; the first barrier below publishes them
     if (MODE != 2) {
         if (tid < NF * 16) { ssc[tid >> 4][tid & 15] = r_sc; ssh[tid >> 4][tid & 15] = r_sh; }
-        if (MODE == 1 && NF * eC * 16 <= WAVES * 64 && tid < NF * eC * 16) pws[tid / (eC * 16)][(tid / 16) % eC][tid & 15] = r_pw;
+        if (MODE == 1) {
+            if (NF * eC * 16 <= WAVES * 64) {
+                if (tid < NF * eC * 16) {
+                    const int f = tid / (eC * 16), nl = tid & 15;
+                    pws[f][(tid / 16) % eC][nl] = (min(fi0 + f, nfr - 1) * 16 + nl < N) ? r_pw : 0.f;
+                }
+            } else {
+                for (int e = tid; e < NF * eC * 16; e += WAVES * 64) {
+                    const int f = e / (eC * 16), c = (e / 16) % eC, nl = e & 15;
+                    const int n = min(fi0 + f, nfr - 1) * 16 + nl;
+                    pws[f][c][nl] = n < N ? nd_ldg(d.pw + (size_t)c * N + n) : 0.f;
+                }
+            }
+        }
     }
 
     // ---- all fragments at once: cross-wave reduction (fixed order) + epilogue, two barriers in total ----

@@ -55,6 +55,14 @@ struct MemberDev {
 
 #define ND_MAX_C 8
 
+// Pointers that come out of descriptor structs are generic to the compiler; loads through them become flat_load, which is
+// counted on vmcnt AND lgkmcnt and cannot be waited on selectively -- the step head's "tables in flight under the reduction"
+// would serialise at the first LDS access.  These casts put the accesses in the global address space.
+typedef const __attribute__((address_space(1))) float* nd_gcf;
+typedef __attribute__((address_space(1))) float* nd_gf;
+#define ND_GC(p) ((nd_gcf)(p))
+#define ND_GW(p) ((nd_gf)(p))
+
 struct StepIO {             // per-launch tensors with a member-major leading stride
     const float* yhat;  size_t yhat_ms;    // [nm][B][C]
     const float* ymean; size_t ymean_ms;   // [nm][B][C]
@@ -102,7 +110,7 @@ __device__ __forceinline__ void nd_reduce_eps(const float* __restrict__ epart, i
 #pragma unroll
     for (int c = 0; c < C; ++c) {
         s[c] = 0.f;
-        const float* row = epart + ((size_t)m * C + c) * NT;
+        nd_gcf row = ND_GC(epart + ((size_t)m * C + c) * NT);
         for (int tl = tid; tl < NT; tl += NT_THREADS) s[c] += row[tl];
     }
 #pragma unroll
@@ -144,34 +152,34 @@ __global__ __launch_bounds__(256) void k_step_head(const MemberDev* __restrict__
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f), cc = a, xe = a;
     float w1[4][C2];
     if (live) {
-        a = *reinterpret_cast<const float4*>(mb.A1 + (size_t)t * F + n);
-        cc = *reinterpret_cast<const float4*>(mb.C1 + (size_t)t * F + n);
-        xe = *reinterpret_cast<const float4*>(mb.xe + nd_pk(b, n, nchF));
-        const float* wrow = mb.lin1_w + (size_t)n * C2;     // 4 consecutive rows = 4*C2 contiguous floats
+        a = nd_ld16<false>(mb.A1 + (size_t)t * F + n);
+        cc = nd_ld16<false>(mb.C1 + (size_t)t * F + n);
+        xe = nd_ld16<false>(mb.xe + nd_pk(b, n, nchF));
+        nd_gcf wrow = ND_GC(mb.lin1_w + (size_t)n * C2);     // 4 consecutive rows = 4*C2 contiguous floats
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int q = 0; q < C2; ++q) w1[j][q] = wrow[j * C2 + q];
     }
     const int par_new = i_step & 1;                       // ybuf parity written by this step
-    float* ynew = mb.ybuf + ((size_t)par_new * maxM + m) * C;
-    const float* yold = mb.ybuf + ((size_t)(par_new ^ 1) * maxM + m) * C;
+    nd_gf ynew = ND_GW(mb.ybuf + ((size_t)par_new * maxM + m) * C);
+    nd_gcf yold = ND_GC(mb.ybuf + ((size_t)(par_new ^ 1) * maxM + m) * C);
     float yv[C], yh[C], ym[C], zz[C], yo[C], eps[C];
     float al = 0.f, s_t = 0.f, s_tm1 = 0.f;
 #pragma unroll
     for (int c = 0; c < C; ++c) {
-        yh[c] = io.yhat[z * io.yhat_ms + (size_t)b * C + c];
+        yh[c] = ND_GC(io.yhat)[z * io.yhat_ms + (size_t)b * C + c];
         eps[c] = 0.f; ym[c] = 0.f; zz[c] = 0.f; yo[c] = 0.f;
     }
     if (mode != ND_HEAD_GIVEN) {
 #pragma unroll
         for (int c = 0; c < C; ++c) {
-            ym[c] = io.ymean[z * io.ymean_ms + (size_t)b * C + c];
-            zz[c] = io.noise[z * io.noise_ms + ((size_t)i_step * M + m) * C + c];
+            ym[c] = ND_GC(io.ymean)[z * io.ymean_ms + (size_t)b * C + c];
+            zz[c] = ND_GC(io.noise)[z * io.noise_ms + ((size_t)i_step * M + m) * C + c];
         }
     }
     if (mode == ND_HEAD_UPDATE) {
-        al = io.alphas[t_prev]; s_t = io.omabs[t_prev]; s_tm1 = io.omabs[t_prev - 1];
+        al = ND_GC(io.alphas)[t_prev]; s_t = ND_GC(io.omabs)[t_prev]; s_tm1 = ND_GC(io.omabs)[t_prev - 1];
 #pragma unroll
         for (int c = 0; c < C; ++c) yo[c] = yold[c];
         nd_reduce_eps<256, C>(mb.epart, NT, m, red, eps);
@@ -179,11 +187,11 @@ __global__ __launch_bounds__(256) void k_step_head(const MemberDev* __restrict__
 #pragma unroll
     for (int c = 0; c < C; ++c) {
         if (mode == ND_HEAD_INIT) yv[c] = zz[c] + ym[c];
-        else if (mode == ND_HEAD_UPDATE) yv[c] = nd_posterior(yo[c], ym[c], eps[c] + mb.lin4_b[c], zz[c], al, s_t, s_tm1);
-        else yv[c] = io.y_in[z * io.yin_ms + (size_t)m * C + c];
+        else if (mode == ND_HEAD_UPDATE) yv[c] = nd_posterior(yo[c], ym[c], eps[c] + ND_GC(mb.lin4_b)[c], zz[c], al, s_t, s_tm1);
+        else yv[c] = ND_GC(io.y_in)[z * io.yin_ms + (size_t)m * C + c];
         if (tid == 0 && blockIdx.x == 0) {
             ynew[c] = yv[c];
-            if (io.seq_out && mode != ND_HEAD_GIVEN) io.seq_out[z * io.seq_ms + ((size_t)i_step * M + m) * C + c] = yv[c];
+            if (io.seq_out && mode != ND_HEAD_GIVEN) ND_GW(io.seq_out)[z * io.seq_ms + ((size_t)i_step * M + m) * C + c] = yv[c];
         }
     }
     if (!live) return;
@@ -202,10 +210,10 @@ __global__ __launch_bounds__(256) void k_step_head(const MemberDev* __restrict__
     h.z = nd_softplus(a.z * u[2] + cc.z) * xe.z;
     h.w = nd_softplus(a.w * u[3] + cc.w) * xe.w;
     if (mb.h16)
-        *reinterpret_cast<f16x4*>(reinterpret_cast<_Float16*>(mb.h1) + nd_pkh(m, n, F >> 5)) =
+        *(__attribute__((address_space(1))) f16x4*)(reinterpret_cast<_Float16*>(mb.h1) + nd_pkh(m, n, F >> 5)) =
             f16x4{(_Float16)h.x, (_Float16)h.y, (_Float16)h.z, (_Float16)h.w};
     else
-        *reinterpret_cast<float4*>(mb.h1 + nd_pk(m, n, nchF)) = h;
+        *(__attribute__((address_space(1))) f32x4*)(mb.h1 + nd_pk(m, n, nchF)) = f32x4{h.x, h.y, h.z, h.w};
 }
 
 static void* head_fn(int C) {
