@@ -11,7 +11,7 @@ import os
 from typing import Optional
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libnd_hip.so")
+LIB_PATH = os.environ.get("ND_LIB_PATH") or os.path.join(HERE, "libnd_hip.so")   # ND_LIB_PATH: a debug build (tools/wg_times.py)
 
 ND_ACT_NONE, ND_ACT_SOFTPLUS, ND_ACT_RELU, ND_ACT_GELU = 0, 1, 2, 3
 ND_DTYPE_F32, ND_DTYPE_F16 = 0, 1

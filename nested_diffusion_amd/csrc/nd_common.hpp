@@ -490,9 +490,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_skinny(SkinnyDesc d0, const Skin
     }
 #ifdef ND_WG_TIMING
     if (tid == 0 && nd_dbg_times) {
-        long long* q = nd_dbg_times + (size_t)blockIdx.x * 3;
+        long long* q = nd_dbg_times + ((size_t)MODE * 8192 + blockIdx.x) * 3;      // one region per MODE: the last launch of each stays
         q[0] = dbg_t0; q[1] = dbg_t1; q[2] = wall_clock64();
-        long long* q2 = nd_dbg_times + (size_t)(4096 + blockIdx.x) * 3;
+        long long* q2 = nd_dbg_times + ((size_t)MODE * 8192 + 4096 + blockIdx.x) * 3;
         q2[0] = dbg_t2; q2[1] = dbg_t3; q2[2] = 0;
     }
 #endif

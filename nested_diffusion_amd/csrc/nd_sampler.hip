@@ -21,6 +21,12 @@
 // ---------------------------------------------------------------------------------------------
 static thread_local std::string g_err;
 extern "C" const char* nd_last_error(void) { return g_err.c_str(); }
+#ifdef ND_WG_TIMING
+// debug builds only (tools/wg_times.py): where k_skinny drops its per-workgroup clocks, 3 x 8192 x 3 int64
+extern "C" int nd_debug_set_wg_times(void* dev_ptr) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(nd_dbg_times), &dev_ptr, sizeof dev_ptr) == hipSuccess ? 0 : -1;
+}
+#endif
 extern "C" const char* nd_version(void) { return "libnd_hip gfx950 f32-mfma r1"; }
 int nd_set_err(int code, const char* fmt, ...) {
     char buf[512];

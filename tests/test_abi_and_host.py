@@ -211,3 +211,18 @@ def test_launch_plans_on_the_host():
     assert lib.nd_gemm_workspace_bytes(8192, 4096, 4096, 0) == 0                       # 4096 tiles: whole rounds only
     assert lib.nd_gemm_workspace_bytes(8, 16, 8, 0) == 0
     assert lib.nd_gemm_workspace_bytes(6272, 768, 768, 1) > 0 and lib.nd_gemm_workspace_bytes(6272, 48, 768, 1) == 0   # fp16: K % 32
+
+
+def test_step_gemm_loops_keep_counted_waits():
+    """ISA check (no GPU): every software-pipelined k_skinny loop must wait with a counted vmcnt and contain no flat_load --
+    a pending flat load (pointer read out of a descriptor table without an address-space cast) or an uncountable load before
+    the loop degrades every wait to vmcnt(0) and silently collapses the pipeline (measured: +5..8 us per launch)."""
+    import shutil
+    import subprocess
+    import sys
+    if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        pytest.skip("hipcc not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_waits.py")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "0 degraded" in r.stdout

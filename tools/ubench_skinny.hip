@@ -314,6 +314,22 @@ __global__ __launch_bounds__(WAVES * 64) void k_stream5(const float* wp_, int nc
     if (t == 123.456f) out[0] = t;
 }
 
+// rewrites the packed x operand the way the step head does: one row m per workgroup, 16-byte pieces at a 256-byte stride
+// (a 128-byte line collects pieces of 8 rows = 8 workgroups, usually on different XCDs)
+__global__ __launch_bounds__(256) void k_scatter_x(const float* __restrict__ x, float* __restrict__ xp, int M, int K) {
+    const int g = blockIdx.z, m = blockIdx.y, n = blockIdx.x * 1024 + threadIdx.x * 4;
+    if (n >= K) return;
+    const float4 v = *reinterpret_cast<const float4*>(x + ((size_t)g * M + m) * K + n);
+    *reinterpret_cast<float4*>(xp + (size_t)g * M * K + nd_pk(m, n, K >> 4)) = v;
+}
+// the same data written as whole lines: a workgroup covers a 16-row tile x 64 columns = 4 contiguous 1-KiB blocks
+__global__ __launch_bounds__(256) void k_tile_x(const float* __restrict__ x, float* __restrict__ xp, int M, int K) {
+    const int g = blockIdx.z, mt = blockIdx.y, c0 = blockIdx.x * 4, tid = threadIdx.x;
+    const int blk = tid >> 6, l = tid & 63, m = mt * 16 + (l & 15), n = (c0 + blk) * 16 + 4 * (l >> 4);
+    const float4 v = *reinterpret_cast<const float4*>(x + ((size_t)g * M + m) * K + n);
+    *reinterpret_cast<float4*>(xp + (size_t)g * M * K + ((size_t)mt * (K >> 4) + c0 + blk) * 256 + l * 4) = v;
+}
+
 __global__ void k_pack(const float* src, float* dst, int R, int K) {  // [R][K] -> [R/16][K/16][64][4]
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;    // float4 index in dst
     const size_t total = (size_t)R * K / 4;
@@ -871,12 +887,12 @@ int main(int argc, char** argv) {
         }
     }
     if (argc > 3 && argv[3][0] == 'T') {      // per-workgroup timing of the library kernel (MODE 0)
-        long long* dbg; CK(hipMalloc(&dbg, 8192 * 3 * 8)); CK(hipMemset(dbg, 0, 8192 * 3 * 8));
+        long long* dbg; CK(hipMalloc(&dbg, 3 * 8192 * 3 * 8)); CK(hipMemset(dbg, 0, 3 * 8192 * 3 * 8));
         CK(hipMemcpyToSymbol(HIP_SYMBOL(nd_dbg_times), &dbg, sizeof dbg));
         for (int rep = 0; rep < 3; ++rep) { if (argv[3][1] == '1') launch_lib<1, 1>(p, G, st); else launch_lib<0, 0>(p, G, st); }
         CK(hipStreamSynchronize(st));
         std::vector<long long> h(8192 * 3);
-        CK(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(h.data(), dbg + (size_t)(argv[3][1] == '1' ? 1 : 0) * 8192 * 3, h.size() * 8, hipMemcpyDeviceToHost));
         const SkinnyLaunch L = nd_skinny_launch<0>(K, N, M, G);
         long long tmin = 1LL << 62; for (unsigned b = 0; b < L.grid.x; ++b) tmin = std::min(tmin, h[b * 3]);
         printf("grid %u workgroups; per-WG (start, loop, total) in us relative to the first start [100 MHz clock]\n", L.grid.x);
@@ -897,6 +913,29 @@ int main(int argc, char** argv) {
         printf("earliest finishers:\n"); for (int i = 0; i < 4; ++i) pr(tot[i].second);
         printf("median:\n"); pr(tot[tot.size() / 2].second);
         printf("latest finishers:\n"); for (size_t i = tot.size() - 8; i < tot.size(); ++i) pr(tot[i].second);
+        return 0;
+    }
+    if (argc > 3 && argv[3][0] == 'P') {      // does the predecessor kernel change the duration of the MODE 0 launch?
+        auto tiny = [&]() { hipLaunchKernelGGL(k_pack, dim3(640), dim3(256), 0, st, x, xp, G * M, K); };   // ~ the step head: small, all CUs
+        hipEvent_t ea[8], eb[8];
+        for (int i = 0; i < 8; ++i) { CK(hipEventCreate(&ea[i])); CK(hipEventCreate(&eb[i])); }
+        auto scatter = [&]() { hipLaunchKernelGGL(k_scatter_x, dim3(K / 1024, M, G), dim3(256), 0, st, x, xp, M, K); };
+        auto tiled = [&]() { hipLaunchKernelGGL(k_tile_x, dim3(K / 64, M / 16, G), dim3(256), 0, st, x, xp, M, K); };
+        for (int var = 0; var < 5; ++var) {
+            double acc = 0; int n = 0;
+            for (int r = 0; r < rounds + 2; ++r) {
+                for (int i = 0; i < 8; ++i) {
+                    if (var == 0) launch_lib<1, 1>(p, G, st); else if (var == 1) tiny(); else if (var == 2) { launch_lib<1, 1>(p, G, st); tiny(); }
+                    else if (var == 3) { launch_lib<1, 1>(p, G, st); scatter(); } else { launch_lib<1, 1>(p, G, st); tiled(); }
+                    CK(hipEventRecord(ea[i], st));
+                    launch_lib<0, 0>(p, G, st);
+                    CK(hipEventRecord(eb[i], st));
+                }
+                CK(hipStreamSynchronize(st));
+                if (r >= 2) for (int i = 0; i < 8; ++i) { float ms; CK(hipEventElapsedTime(&ms, ea[i], eb[i])); acc += ms; ++n; }
+            }
+            printf("MODE 0 launch after %-34s: %.1f us\n", var == 0 ? "a MODE 1 launch" : var == 1 ? "a small kernel" : var == 2 ? "MODE 1 + small kernel" : var == 3 ? "MODE 1 + x rewritten in 16-B pieces" : "MODE 1 + x rewritten in whole lines", acc / n * 1e3);
+        }
         return 0;
     }
     if (argc > 3 && argv[3][0] == 's') {
