@@ -211,3 +211,28 @@ def test_perturbation_ops_vs_reference_goldens():
     d = P.down_up_sample(big, 4)
     assert d.shape == big.shape
     assert (d.cpu() - ref_cpu.down_up_sample(big.cpu(), 4)).abs().max() < 3e-7
+
+
+def test_linear_random_shapes_cover_launch_geometry():
+    """40 random (M, K, N) shapes in both operand dtypes: every combination of fragments-per-workgroup (1..6, with and without
+    a remainder), leftover k-chunks, k-slabs and row groups the launcher can pick must give the same numbers as torch."""
+    import random
+    from nested_diffusion_amd import ops
+    rnd = random.Random(7)
+    for it in range(40):
+        half = it % 2 == 1
+        kq = 32 if half else 16
+        M = rnd.choice([1, 2, 7, 16, 17, 31, 32, 33, 48, 64, 65, 70])
+        K = kq * rnd.randint(1, 80) if it % 5 else kq * rnd.randint(1024 // kq, 40000 // kq)
+        N = rnd.choice([1, 2, 15, 16, 17, 100, 255, 256, 257, 600, 1000, 1536, 4096]) if K < 5000 else rnd.choice([3, 64, 130, 256])
+        g = torch.Generator().manual_seed(it)
+        x = torch.randn(M, K, generator=g)
+        w = torch.randn(N, K, generator=g) / K ** 0.5
+        b = torch.randn(N, generator=g)
+        s = torch.rand(N, generator=g) + 0.5
+        pw = ops.PackedWeight(w.cuda(), dtype="f16" if half else "f32")
+        out = ops.linear(x.cuda(), pw, b.cuda(), act="relu", scale=s.cuda())
+        xr, wr = (x.half().double(), w.half().double()) if half else (x.double(), w.double())
+        ref = F.relu(s * (xr @ wr.T).float() + b)
+        err = (out.cpu().double() - ref.double()).abs().max().item()
+        assert err <= 2e-5 * max(1.0, ref.abs().max().item()), (it, M, K, N, half, err)
