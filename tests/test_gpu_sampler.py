@@ -165,9 +165,33 @@ def test_reference_default_batch_70_and_row_groups():
         assert (y0[j * B:(j + 1) * B] - ref).abs().max() < 5e-5 * max(1.0, ref.abs().max())
 
 
+@pytest.mark.parametrize("K,Fd", [(3, 3200), (5, 1376), (2, 4112)])
+def test_members_with_uneven_fragment_dealing(K, Fd):
+    """Multi-member launches whose fragments do not divide evenly over a member's workgroups: F = 3200 with 3 members gives
+    85 workgroups per member, 30 of them with 3 fragments and 55 with 2; F = 1376 with 5 members 51 workgroups with 2 or 1;
+    F = 4112 with 2 members 128 workgroups with 3 or 2 -- the NF / NF-1 forms of k_skinny side by side in one launch."""
+    from nested_diffusion_amd.engine import EnsembleEngine
+    D, H, C, T, B = 64, 48, 2, 3, 6
+    ps = [ref_cpu.init_cond_model_params(D, H, Fd, C, T, True, seed=170 + k) for k in range(K)]
+    eng = EnsembleEngine(C, D, H, Fd, T, n_members=K, max_batch=B)
+    for k, p in enumerate(ps):
+        eng.load_member(k, p)
+    alphas, omabs = ref_cpu.schedule_tables("linear", T, 1e-4, 0.02)
+    eng.set_schedule(alphas, omabs)
+    g = torch.Generator().manual_seed(4)
+    x = torch.rand(B, D, generator=g)
+    yhat = torch.softmax(torch.randn(K, B, C, generator=g), -1)
+    noise = torch.randn(K, T, B, C, generator=g)
+    eng.encode(x)
+    y0 = eng.sample(yhat.cuda(), yhat.cuda(), noise.cuda()).cpu()
+    for k, p in enumerate(ps):
+        ref = ref_cpu.p_sample_loop(p, x, yhat[k], yhat[k], T, alphas, omabs, noise[k])
+        assert (y0[k] - ref).abs().max() < 1e-4 * max(1.0, ref.abs().max()), k
+
+
 def test_five_members_uneven_fragment_ranges():
-    """K = 5 members with F = 80 (5 fragments each): workgroups whose fragment range crosses a member boundary
-    take the two-activation path of k_skinny."""
+    """K = 5 members with F = 80 (5 fragments each): every member's fragments go to its own workgroups (one fragment each
+    here); a workgroup never mixes members."""
     from nested_diffusion_amd.engine import EnsembleEngine
     D, H, Fd, C, T, B = 64, 48, 80, 2, 5, 9
     ps = [ref_cpu.init_cond_model_params(D, H, Fd, C, T, True, seed=70 + k) for k in range(5)]
