@@ -246,9 +246,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_skinny(SkinnyDesc d0, const Skin
     const int glast = ngroups > 0 ? ngroups - 1 : 0;
 
     // MAIN LOOP.  Two register stages (A, B), each a whole group of U chunks (NF weight + MT activation fragments), used
-    // alternately with no copies: the loads of the next group are issued, THEN the MFMAs of the current one run, so every
-    // wave keeps one group in flight under its arithmetic.  The scheduling barriers pin that order (left alone, the
-    // compiler sinks the loads below the MFMAs to save registers and then waits on them at once).
+    // alternately with no copies: while the MFMAs of the current group run, the loads of the next one are issued, so every
+    // wave keeps one group in flight under its arithmetic.  Scheduling barriers pin that order (left alone, the compiler
+    // sinks the loads below the MFMAs to save registers and then waits on them at once).
     // FULL = false (a workgroup with NF - 1 fragments): the last fragment slot is neither loaded nor multiplied.
     const int lane4 = lane * 4;
     auto run = [&](auto ntc, auto fullc) {
@@ -286,16 +286,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_skinny(SkinnyDesc d0, const Skin
         auto G = [&](int i) { return min(wave + i * WAVES, glast); };      // group of this wave's i-th turn (clamped)
         int i = 0;
         if (ngw > 0) LD(wA, xA, G(0));
-        // Steady state.  The next stage's loads are either issued in a block before the current stage's MFMAs, or spread
-        // through them (one load per MR MFMAs: the matrix pipe never waits for the ~150 cycles of load issue).  Measured
-        // (K=5, M=32, in the sampler graph): spread is 3 us faster for MODE 0 and 3 us SLOWER for MODE 1 -- same loop, the
-        // compiler's schedule around it differs -- so it is chosen per mode.
-#ifndef ND_MR1
-#define ND_MR1 0
-#endif
-        constexpr bool SPREAD = ND_MR1 >= 0;
-        constexpr int NL = U * (NFA + MT), NM = U * (H ? 1 : 4) * NFA * MT;
-        constexpr int MR = (MODE == 1 && ND_MR1 > 0) ? ND_MR1 : (NM / NL > 0 ? NM / NL : 1);
+        // Steady state.  The next stage's loads are spread through the current stage's MFMAs (one load per MR MFMAs), so the
+        // matrix pipe never waits for the ~150 cycles of load issue: -3 us per launch against issuing them in a block first.
+        constexpr int NL = U * (NFA + MT), NM = U * (H ? 1 : 4) * NFA * MT, MR = NM / NL > 0 ? NM / NL : 1;
 #define ND_MIX()                                                                                     \
         _Pragma("unroll") for (int q_ = 0; q_ < NL; ++q_) {                                          \
             __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                       \
@@ -304,13 +297,11 @@ __global__ __launch_bounds__(WAVES * 64) void k_skinny(SkinnyDesc d0, const Skin
         __builtin_amdgcn_sched_barrier(0);
         for (; i + 1 < ngw; i += 2) {
             LD(wB, xB, G(i + 1));
-            if (!SPREAD) __builtin_amdgcn_sched_barrier(0);
             MMA(wA, xA);
-            if (SPREAD) { ND_MIX() } else __builtin_amdgcn_sched_barrier(0);
+            ND_MIX()
             LD(wA, xA, G(i + 2));          // i + 2 == ngw on the last pair of an even count: re-reads a valid group, unused
-            if (!SPREAD) __builtin_amdgcn_sched_barrier(0);
             MMA(wB, xB);
-            if (SPREAD) { ND_MIX() } else __builtin_amdgcn_sched_barrier(0);
+            ND_MIX()
         }
 #undef ND_MIX
         if (i < ngw) MMA(wA, xA);
