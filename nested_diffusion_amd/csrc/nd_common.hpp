@@ -216,7 +216,6 @@ __global__ __launch_bounds__(WAVES * 64) void k_skinny(SkinnyDesc d0, const Skin
 
     // Epilogue operands are requested NOW (registers; parked in LDS after the main loop): the scale/shift entries of the
     // workgroup's output columns and the lin4 rows of MODE 1.
-    constexpr int EPT = (MT * 256 + WAVES * 64 - 1) / (WAVES * 64);   // epilogue elements per thread
     __shared__ float ssc[NF][16], ssh[NF][16];
     __shared__ float pws[MODE == 1 ? NF : 1][MODE == 1 ? 8 : 1][16];
     const int eact = d.act, eC = d.C, epacked = d.out_packed;
@@ -531,6 +530,19 @@ static __global__ __launch_bounds__(256) void k_splitk_epilogue(SplitKEpiDesc d0
 }
 
 // ---- host helpers ---------------------------------------------------------------------------
+// Compute units of the CURRENT device (256 on an MI355X in SPX mode, fewer under CPX partitioning), queried once per
+// device.  Launch geometry is a pure function of (shape, CU count); 256 is assumed when no device is visible (host-only
+// plan introspection in the build container).
+static inline int nd_num_cus() {
+    static int cached[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cached[dev] == 0) {
+        int n = 0;
+        cached[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+    }
+    return cached[dev];
+}
 static inline int nd_pick_mt(int M) { return M <= 16 ? 1 : (M <= 32 ? 2 : 4); }
 static inline bool nd_use_splitk(int K) { return K >= 16384; }
 
@@ -549,8 +561,9 @@ static inline SkinnyLaunch nd_skinny_launch(int K, int N, int M, int nm, int hal
     const int nfr = (N + 15) / 16, nch = half ? K / 32 : K / 16;
     const int mgroups = (M + 16 * mt - 1) / (16 * mt);
     const int nfmax = mt == 4 ? 3 : 6;             // register budget (accumulators + two stages)
+    const int ncu = nd_num_cus();
     // workgroups per member: as many as keep the grid within one workgroup per CU, but no workgroup above nfmax fragments
-    int wpm = 256 / nm;
+    int wpm = ncu / nm;
     if (wpm < 1) wpm = 1;
     if (wpm > nfr) wpm = nfr;
     while ((nfr + wpm - 1) / wpm > nfmax) ++wpm;
@@ -564,10 +577,10 @@ static inline SkinnyLaunch nd_skinny_launch(int K, int N, int M, int nm, int hal
         for (int nfc = nfmax; nfc >= 1; --nfc) {
             const int w = (nfr + nfc - 1) / nfc;
             const int wgs = nm * w * mgroups;
-            int sc = wgs >= 256 ? 1 : 256 / wgs;
+            int sc = wgs >= ncu ? 1 : ncu / wgs;
             while (sc > 1 && nch / sc < 64) --sc;          // keep every slab >= 64 chunks deep
             const long tot = (long)wgs * sc;
-            const double util = tot >= 256 ? (double)tot / (256.0 * ((tot + 255) / 256)) : tot / 256.0;
+            const double util = tot >= ncu ? (double)tot / ((double)ncu * ((tot + ncu - 1) / ncu)) : tot / (double)ncu;
             const double nfe = (double)nfr / w;
             const double cost = (1.0 + 0.3 * mt / nfe) / util;
             if (cost < best - 1e-9) { best = cost; bw = w; bs = sc; }

@@ -328,12 +328,13 @@ __global__ __launch_bounds__(256) void k_gemm_fixup(const float* __restrict__ pa
 // tiles % 256 remainder is cut into `split` k-slabs where that shortens the last round (needs the workspace).
 #define GT_BM 128
 #define GT_BN 64
-#define GT_CUS 256
+#define GT_CUS (nd_num_cus())
 struct GemmPlan { int tiles, n_full, rem, split; size_t ws_bytes; };
 static GemmPlan nd_gemm_plan(int M, int K, int N, int bk = GB_K) {
     GemmPlan p{};
     p.tiles = ((M + GT_BM - 1) / GT_BM) * ((N + GT_BN - 1) / GT_BN);
-    p.n_full = (p.tiles / GT_CUS) * GT_CUS;
+    const int ncu = GT_CUS;
+    p.n_full = (p.tiles / ncu) * ncu;
     p.rem = p.tiles - p.n_full;
     p.split = 1;
     const int nk = K / bk;
@@ -341,9 +342,9 @@ static GemmPlan nd_gemm_plan(int M, int K, int N, int bk = GB_K) {
         // tail length in tile-times: ceil(rem * s / 256) / s ; take the smallest s that gets within 10 % of the best
         double best = 1e9;
         const int cand[] = {1, 2, 3, 4, 5, 6, 8};
-        for (int s : cand) if (nk / s >= 8) best = fmin(best, (double)((p.rem * s + GT_CUS - 1) / GT_CUS) / s);
+        for (int s : cand) if (nk / s >= 8) best = fmin(best, (double)((p.rem * s + ncu - 1) / ncu) / s);
         for (int s : cand)
-            if (nk / s >= 8 && (double)((p.rem * s + GT_CUS - 1) / GT_CUS) / s <= best * 1.1 + 1e-9) { p.split = s; break; }
+            if (nk / s >= 8 && (double)((p.rem * s + ncu - 1) / ncu) / s <= best * 1.1 + 1e-9) { p.split = s; break; }
     }
     p.ws_bytes = p.split > 1 ? (size_t)p.rem * p.split * GT_BM * GT_BN * sizeof(float) : 0;
     return p;

@@ -39,6 +39,16 @@ def init_from_env(backend: str = None) -> Tuple[int, int, int]:
     return rank, local, world
 
 
+def shutdown() -> None:
+    """Leave the process group (no-op for single-process runs); called from main()'s finally block so that a rank that
+    failed does not leave its peers blocked in a collective."""
+    if td.is_available() and td.is_initialized():
+        try:
+            td.destroy_process_group()
+        except Exception:
+            pass
+
+
 def shard_bounds(n: int, rank: int, world: int) -> Tuple[int, int]:
     """Contiguous, balanced split of n rows: the first n % world ranks get one extra row."""
     if world < 1 or not (0 <= rank < world):

@@ -137,10 +137,16 @@ def parse_config(args):
     device = torch.device(f"cuda:{local}")
     logging.info("Using device: {}".format(device))
     new_config.device = device
-    torch.manual_seed(args.seed)
-    np.random.seed(args.seed)
-    torch.cuda.manual_seed_all(args.seed)
+    set_seed(args.seed)
     return new_config, logger
+
+
+def set_seed(seed: int) -> None:
+    """main.py:277-281 (torch, numpy, cuda); the runner's own set_seed (classification_train_separately.py:31-38, from
+    Diffusion.__init__) adds python `random`, which random_cover_new's rectangles come from.  All ranks of a multi-GPU
+    run use the same seed: the runner draws per WHOLE batch and slices its shard (runner.draw_noise / shard_of_batch)."""
+    from .runner import set_seed as runner_set_seed
+    runner_set_seed(seed)
 
 
 def main(argv=None) -> int:
@@ -149,13 +155,18 @@ def main(argv=None) -> int:
         args.seed = random.randint(0, 10000)                      # main.py:163-164
     args.doc = args.doc + "/split_" + str(args.split)             # main.py:384
     from . import dist as nd_dist
-    nd_dist.init_from_env()
-    config, logger = parse_config(args)
+    _, _, world = nd_dist.init_from_env()
+    failed = False
+    try:
+        config, logger = parse_config(args)
+    except BaseException:
+        nd_dist.shutdown()
+        raise
     logging.info("Writing log file to {}".format(args.log_path))
     logging.info("Exp instance id = {}".format(os.getpid()))
-    if args.loss != 'card_onehot_conditional':
-        raise NotImplementedError("Invalid loss option")          # main.py:310-311
     try:
+        if args.loss != 'card_onehot_conditional':
+            raise NotImplementedError("Invalid loss option")      # main.py:310-311
         from .runner import Diffusion
         runner = Diffusion(args, config, device=config.device)
         start_time = time.time()
@@ -171,11 +182,16 @@ def main(argv=None) -> int:
             raise NotImplementedError("training is outside the accelerated hot path")
         logging.info("\n{} procedure finished. It took {:.4f} minutes.\n\n\n".format(procedure, (time.time() - start_time) / 60))
     except Exception:
-        logging.error(traceback.format_exc())                     # main.py:377-378: logged, exit code stays 0
-    for handler in logger.handlers[:]:
-        logger.removeHandler(handler)
-        handler.close()
-    return 0
+        logging.error(traceback.format_exc())                     # main.py:377-378: logged, exit code stays 0 ...
+        failed = True
+    finally:
+        nd_dist.shutdown()
+        for handler in logger.handlers[:]:
+            logger.removeHandler(handler)
+            handler.close()
+    # ... for a single process, as in the reference.  A rank of a multi-GPU run that failed must not look successful: its
+    # peers would wait in the batch's all-gather until the RCCL timeout and torchrun would report rc 0.
+    return 1 if (failed and world > 1) else 0
 
 
 if __name__ == "__main__":

@@ -34,6 +34,17 @@ def majority_voting_for_mc_samples(predictions: Sequence[torch.Tensor]) -> torch
     return vote.to(predictions[0].device)
 
 
+def set_seed(seed) -> None:
+    """:31-38, called from Diffusion.__init__ (:198): torch (CPU + every GPU), numpy and python `random`."""
+    import random
+    import numpy as np
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(seed)
+    np.random.seed(seed)
+    random.seed(seed)
+
+
 def temperature_for(dataset: str) -> float:
     """classification_train_separately.py:318-327."""
     if dataset in CHEST:
@@ -50,6 +61,8 @@ class Diffusion(object):
         weights; otherwise they are read from the reference's checkpoint layout."""
         self.args, self.config = args, config
         self.seed = getattr(args, "seed", 0)
+        if self.seed is not None:
+            set_seed(self.seed)                                              # :198
         # operand dtype of the weight-streaming layers: --fp16 (or model.operand_dtype: f16 in the YAML) selects the fp16
         # mode of BASELINE config 5; the reference itself only has fp32
         self.operand_dtype = "f16" if getattr(args, "fp16", False) else getattr(config.model, "operand_dtype", "f32")
@@ -158,6 +171,23 @@ class Diffusion(object):
         prob, vote, probs = ops.aggregate(samples, self.temperature, return_probs=True)  # :786, :789
         return {"samples": samples, "vote": vote, "prob": prob, "probs": probs, "yhat": yhat}
 
+    # ---- world-size independent randomness ---------------------------------------------------------
+    def draw_noise(self, B_total: int, lo: int, hi: int, mc: Optional[int] = None) -> torch.Tensor:
+        """The sampler's draws for rows [lo, hi) of a test batch of B_total images: [K, T, (hi-lo)*mc, C].
+        Every rank holds the same --seed (the reference's set_seed, :31-38), draws the draws of the WHOLE batch
+        [K, T, mc, B_total, C] and keeps its own images, so image i sees the same K*T*mc draws at any world size
+        (and rows of different ranks are not copies of each other)."""
+        mc = mc or self.mc_trials
+        K, T, C = len(self.members), self.num_timesteps, self.config.data.num_classes
+        z = torch.randn(K, T, mc, B_total, C, device=self.device)
+        return z[:, :, :, lo:hi].reshape(K, T, mc * (hi - lo), C).contiguous()
+
+    def shard_of_batch(self, images_raw: torch.Tensor, lo: int, hi: int) -> torch.Tensor:
+        """Perturb the WHOLE batch (:726-737; every rank makes the same host/device RNG calls in the reference's order,
+        so the windows and the noise of image i do not depend on the world size), then keep this rank's rows."""
+        images = self.perturb(images_raw.to(self.device, torch.float32))
+        return images[lo:hi].contiguous()
+
     # ---- temperature calibration (:449-629, driven by main.py:356-361) ---------------------------
     def test_calibrate(self, temp=None, test_loader=None):
         """ECE of the ensemble at scaling temperature `temp` on the validation set (:449-629).  The reference
@@ -178,8 +208,8 @@ class Diffusion(object):
                 self.load_noise_estimators(max_batch=max(hi - lo, 1))
             samples, targets = [], []
             for images_raw, target in test_loader:
-                images = self.perturb(images_raw[lo:hi].to(self.device, torch.float32))
-                out = self.predict_batch(images)
+                images = self.shard_of_batch(images_raw, lo, hi)
+                out = self.predict_batch(images, noise=self.draw_noise(images_raw.shape[0], lo, hi))
                 S = out["samples"].shape[0]
                 flat = out["samples"].permute(1, 0, 2).reshape(hi - lo, -1).contiguous()      # [B_local, S*C]
                 flat = nd_dist.all_gather_rows(flat, B, world)
@@ -230,9 +260,8 @@ class Diffusion(object):
         mv_class, target_class, prob_mc, piw_mc, var_mc = [], [], [], [], []
         n_step_img, t0 = 0, time.time()
         for images_raw, target in test_loader:
-            images = images_raw[lo:hi].to(self.device, torch.float32)
-            images = self.perturb(images)                                    # :726-737
-            out = self.predict_batch(images)
+            images = self.shard_of_batch(images_raw, lo, hi)                 # :726-737
+            out = self.predict_batch(images, noise=self.draw_noise(images_raw.shape[0], lo, hi))
             # spread of the K*mc per-sample probabilities per image (what the reference keeps in pred_mc, quirk Q4)
             piw, var = ops.sample_stats(out["probs"])
             packed = torch.cat([out["prob"], piw, var, out["vote"].to(torch.float32)[:, None]], dim=1)

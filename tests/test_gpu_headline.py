@@ -1,0 +1,97 @@
+"""Parity at the REAL sizes of the headline configuration (BASELINE configs[2]): ViT-B/16 prefix (768 wide, 12 heads, 196
+tokens), five 150528->4096->2048->128->2 mapping MLPs, five noise estimators at D=150528, F=H=4096, T=100, B=32 -- the whole
+hot path as ONE number: max |class-probability delta| between the HIP path (through the C ABI) and the CPU oracle on
+identical weights, images and noise.  Reference: classification_train_separately.py:330-348 (conditioner), :749-794 (hot
+loop).  Weights are synthetic (seeded, generated on the GPU, copied to the host for the oracle)."""
+import argparse
+import time
+
+import pytest
+import torch
+
+from oracle import ref_cpu
+
+pytestmark = pytest.mark.gpu
+
+K, T, B, C = 5, 100, 32, 2
+D, H, F = 3 * 224 * 224, 4096, 4096
+
+
+def ns(**kw):
+    return argparse.Namespace(**kw)
+
+
+@pytest.fixture(scope="module")
+def headline():
+    from nested_diffusion_amd import synthetic
+    from nested_diffusion_amd.mapping import Classifier, GuidingConditioner, VisionTransformer
+    from nested_diffusion_amd.runner import Diffusion
+    dev = "cuda"
+    cfg = ns(data=ns(dataset="ChestXRay", num_classes=C), model=ns(data_dim=D, hidden_dim=H, feature_dim=F, arch="linear"),
+             diffusion=ns(timesteps=T, beta_schedule="linear", beta_start=1e-4, beta_end=0.02, aux_cls=ns(arch="sevit"),
+                          trained_aux_cls_ckpt_path="", trained_diffusion_ckpt_path=[[]], include_guidance=True),
+             testing=ns(batch_size=B))
+    vit_sd = synthetic.vit_state(seed=7, device=dev)
+    mlp_sd = [synthetic.classifier_state(196 * 768, seed=2000 + k, device=dev) for k in range(K)]
+    states = [synthetic.cond_model_state(D, H, F, C, T, seed=1000 + k, device=dev) for k in range(K)]
+    cond = GuidingConditioner(VisionTransformer(vit_sd, 12, dev), [Classifier(m, dev) for m in mlp_sd])
+    runner = Diffusion(ns(seed=1234, mc_trials=1), cfg, device=dev, conditioner=cond, noise_estimator_states=list(states))
+    runner.load_noise_estimators(max_batch=B, mc_trials=1)
+    cpu = lambda sd: {k: v.cpu() for k, v in sd.items()}
+    host = {"vit": cpu(vit_sd), "mlps": [cpu(m) for m in mlp_sd], "members": [cpu(s) for s in states]}
+    del vit_sd, mlp_sd, states
+    torch.cuda.empty_cache()
+    return runner, host
+
+
+def test_conditioner_vit_b16_full_size_vs_oracle(headline):
+    """compute_guiding_prediction at ViT-B/16 dims with five full-size mapping MLPs vs the AS-WRITTEN oracle (prefix
+    recomputed per member, :336-345).  Every logit within 2e-5 relative (to the largest logit), softmaxed y-hat within 1e-5."""
+    runner, host = headline
+    x = torch.rand(4, 3, 224, 224, generator=torch.Generator().manual_seed(5))
+    got = runner.compute_guiding_prediction(x.cuda(), include_full_vit=True)
+    ref = ref_cpu.compute_guiding_prediction(host["vit"], host["mlps"], x, 12, 12, full_vit=True, share_prefix=False)
+    assert len(got) == len(ref) == K + 1
+    worst_l = worst_p = 0.0
+    for k in range(K + 1):
+        g, r = got[k].cpu(), ref[k]
+        rel = (g - r).abs().max().item() / max(1.0, r.abs().max().item())
+        dp = (torch.softmax(g, 1) - torch.softmax(r, 1)).abs().max().item()
+        worst_l, worst_p = max(worst_l, rel), max(worst_p, dp)
+        assert rel < 2e-5, (k, rel)
+        assert dp < 1e-5, (k, dp)
+    print(f"conditioner ViT-B/16 + 5 MLPs (150528 wide), B=4: max rel logit err {worst_l:.2e}, max |softmax delta| {worst_p:.2e}")
+
+
+def test_headline_config_end_to_end_class_probability_delta(headline):
+    """K=5, T=100, B=32, full dims: predict_batch with supplied noise vs ref_cpu.ensemble_predict.  hoist=True (the
+    encoder evaluated once per member) is bit-identical to the as-written loop on the CPU
+    (tests/test_oracle_golden.py::test_sampler_small_bit_exact); the conditioner is the as-written form.
+    Criterion (BASELINE north_star): class probabilities within 1e-3; votes equal."""
+    runner, host = headline
+    g = torch.Generator().manual_seed(77)
+    x = torch.rand(B, 3, 224, 224, generator=g)
+    noise = torch.randn(K, 1, T, B, C, generator=g)                       # oracle layout [K, mc, T, B, C]
+    out = runner.predict_batch(x.cuda(), noise=noise.permute(0, 2, 1, 3, 4).reshape(K, T, B, C).cuda(), mc_trials=1)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    logits = ref_cpu.compute_guiding_prediction(host["vit"], host["mlps"], x, 12, 12, full_vit=False, share_prefix=False)
+    yhat = [torch.softmax(l, dim=1) for l in logits]
+    alphas, omabs = ref_cpu.schedule_tables("linear", T, 1e-4, 0.02)
+    raw, vote, prob = ref_cpu.ensemble_predict(host["members"], x.flatten(1), yhat, T, alphas, omabs, noise,
+                                               runner.temperature, hoist=True)
+    cpu_s = time.time() - t0
+    ref = torch.stack(raw)
+    got = out["samples"].cpu()
+    d_yhat = (out["yhat"].cpu() - torch.stack(yhat)).abs().max().item()
+    d_y0 = (got - ref).abs().max().item()
+    d_prob = (out["prob"].cpu() - prob).abs().max().item()
+    print(f"headline K={K} T={T} B={B}: max |class-prob delta| = {d_prob:.3e}, max |y0 delta| = {d_y0:.3e} "
+          f"(|y0| max {ref.abs().max().item():.2f}), max |yhat delta| = {d_yhat:.3e}; oracle took {cpu_s:.1f} s")
+    assert d_prob <= 1e-3
+    assert d_y0 < 1e-4 * max(1.0, ref.abs().max().item())
+    # vote = argmax of raw y_0 (:786): equal wherever the oracle's top-2 margin is not inside the y_0 error itself
+    margin = (ref.topk(2, dim=2).values[..., 0] - ref.topk(2, dim=2).values[..., 1]).amin(dim=0)
+    safe = margin > 10 * d_y0
+    assert safe.sum() >= B - 2
+    assert torch.equal(out["vote"].cpu()[safe], vote[safe])

@@ -171,3 +171,33 @@ def test_isic_config_t1000_vs_oracle():
     tame = (ref.abs().amax(dim=(0, 2)) < 50)
     if tame.any():
         assert (out["prob"].cpu() - prob)[tame].abs().max() < 1e-3
+
+
+def test_calibrate_ece_equals_oracle_on_cached_samples():
+    """Diffusion.test_calibrate(temp) (:449-629) for three temperatures == the oracle's compute_ensemble_confidence (:612)
+    -> compute_ece (:619, with its second convert_to_prob) on the SAME raw samples (the cached draws of the first call).
+    ECE is a sum of per-bin |acc - conf| * share: tolerance 2e-6 (fp32 means of <= 48 values in [0,1])."""
+    from nested_diffusion_amd.mapping import Classifier, GuidingConditioner, VisionTransformer
+    from nested_diffusion_amd.runner import Diffusion
+    embed, heads, depth, img, patch, K, B, T, mc, C = 128, 2, 5, 32, 16, 5, 16, 8, 3, 2
+    D, H, Fd = 3 * img * img, 64, 64
+    vp = ref_cpu.init_vit_params(embed=embed, depth=depth, patch=patch, img=img, seed=23)
+    n_tok = (img // patch) ** 2
+    mlps = [ref_cpu.init_classifier_params(n_tok * embed, widths=(64, 32, 16), seed=220 + i) for i in range(K)]
+    members = [ref_cpu.init_cond_model_params(D, H, Fd, C, T, True, seed=240 + i) for i in range(K)]
+    cfg = small_config(D, H, Fd, C, T, B, dataset="ChestXRayValidate")
+    cond = GuidingConditioner(VisionTransformer(vp, heads), [Classifier(m) for m in mlps])
+    runner = Diffusion(ns(seed=5, mc_trials=mc), cfg, device="cuda", conditioner=cond, noise_estimator_states=members)
+    g = torch.Generator().manual_seed(31)
+    loader = [(torch.rand(B, 3, img, img, generator=g), torch.randint(0, C, (B,), generator=g)) for _ in range(3)]
+    eces = {}
+    for temp in (0.1737, 0.2555, 0.9):
+        eces[temp] = runner.test_calibrate([temp], test_loader=loader)
+        assert runner.temperature == pytest.approx(temp)
+    samples, targets = runner._calib_cache                               # [K*mc, 3*B, C] raw y_0, [3*B]
+    assert samples.shape == (K * mc, 3 * B, C) and targets.shape == (3 * B,)
+    for temp, got in eces.items():
+        conf = ref_cpu.compute_ensemble_confidence([s.clone() for s in samples.cpu()], temp)
+        ref = float(ref_cpu.compute_ece_as_reference(conf, targets.cpu(), temp))
+        assert abs(got - ref) < 2e-6, (temp, got, ref)
+    assert len({round(v, 6) for v in eces.values()}) > 1                  # the objective does depend on the temperature
