@@ -167,6 +167,13 @@ int nd_linear(const float *x_dev, const void *w_packed_dev, const float *scale_d
  * mode 0 fused activation, 1 lin3+lin4 projection, 2 split-K partial sums. */
 int nd_skinny_plan(int K, int N, int M, int n_members, int dtype, int mode, int *out6);
 
+/* Which kernel one ConditionalLinear block of the sampler (latent_model.py:178-184; K = N = feature_dim) runs at
+ * M = B * mc_trials rows (mc_trials = 20 at classification_train_separately.py:770-771, batch_size 70 in
+ * configs/chest_x_ray.yml:66 -> M = 1400), host only.  out8 = {0 weight-streaming k_skinny | 1 LDS-tiled k_cond_gemm
+ * (M > 128 rows, fp32 operands), workgroups of the tiled launch, whole tiles, remainder tiles, k-split of the remainder,
+ * partial sums per (row, class) handed to the step head, 128-row tiles over M, over N}. */
+int nd_step_plan(int feature_dim, int M, int n_members, int dtype, int *out8);
+
 /* Large-M GEMM for the ViT blocks: out[M,N] = act(x[M,K] . W[N,K]^T + bias[n]) (+ residual[M,N]).
  * timm 0.4.12 Attention.qkv / proj, Mlp.fc1 (GELU) / fc2, PatchEmbed.proj as GEMM
  * (call sites classification_train_separately.py:337-340).

@@ -82,6 +82,7 @@ SIGNATURES = {
     "nd_linear_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "nd_linear": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "nd_skinny_plan": (_i, [_i, _i, _i, _i, _i, _i, C.POINTER(_i)]),
+    "nd_step_plan": (_i, [_i, _i, _i, _i, C.POINTER(_i)]),
     "nd_gemm_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "nd_gemm_bias_act": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "nd_layernorm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp]),

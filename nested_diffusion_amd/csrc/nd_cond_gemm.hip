@@ -1,0 +1,254 @@
+// nd_cond_gemm.hip -- the LDS-tiled large-M ConditionalLinear kernels (design notes: nd_cond_gemm.hpp).  gfx950 only.
+// Built with -mllvm -amdgpu-mfma-vgpr-form (nested_diffusion_amd/build.py).
+#include "nd_cond_gemm.hpp"
+
+// which 128 x 128 tile a workgroup owns, and (slab >= 0) which k-slab of it
+struct CondGemmTile { int member, tm, tn, slab, rem_index; };
+
+__device__ __forceinline__ CondGemmTile cg_decode(int bid, int n_full, int split, int TM, int TN) {
+    CondGemmTile tl;
+    tl.slab = -1; tl.rem_index = 0;
+    if (bid < n_full) {
+        // blocks b and b + 8 share an XCD (round-robin dispatch): XCD x takes the contiguous run of tiles [x*q, (x+1)*q)
+        const int q = n_full / 8, r = n_full % 8, xcd = bid % 8, loc = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    } else {
+        const int j = bid - n_full;
+        tl.rem_index = j / split;
+        tl.slab = j % split;
+        bid = n_full + tl.rem_index;
+    }
+    const int per = TM * TN;
+    tl.member = bid / per;
+    const int r2 = bid - tl.member * per;
+    tl.tn = r2 / TM;
+    tl.tm = r2 - tl.tn * TM;
+    return tl;
+}
+
+// Epilogue of one wave's 64 x 64 sub-tile.  acc[i][j] = D of (n-fragment i, m-fragment j): lane l holds the 4 consecutive
+// output columns n = 16*nf + 4*(l>>4) + r of activation row m = 16*mf + (l&15).
+//   MODE 0: v = act(scale[t,n] * acc + shift[t,n]) -> out.  out_packed 1: frag16 [M][N] -- element (m, n) of block (mf, nf)
+//           lives at lane (m%16) + 16*((n%16)/4), slot n%4: exactly this lane's float4, one coalesced 1 KiB store per
+//           fragment.  out_packed 0: row-major.
+//   MODE 1: the same v is not stored; part[m, c, 2*tn + wn] = sum over the wave's 64 columns of pw[c, n] * v  (lin3 +
+//           unetnorm3 + softplus + lin4, latent_model.py:181-184); summed r -> i in-lane, then across the 4 lane groups.
+template <int MODE>
+__device__ __forceinline__ void cg_epilogue(f32x4 (&acc)[4][4], const SkinnyDesc& d, int M, int t, int tm, int tn, int wn, int wm,
+                                            int lane, int ntl) {
+    const int N = d.N, nfr = (N + 15) >> 4, mfr = (M + 15) >> 4;
+    const int g = lane >> 4, li = lane & 15;
+    float sc[4][4], sh[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = min((tn * CG_F + wn * 4 + i) * 16 + 4 * g + r, N - 1);
+            sc[i][r] = d.scale ? nd_ldg(d.scale + (size_t)t * N + n) : 1.0f;
+            sh[i][r] = d.shift ? nd_ldg(d.shift + (size_t)t * N + n) : 0.0f;
+        }
+    const int act = d.act;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float u = sc[i][r] * acc[i][j][r] + sh[i][r];
+                acc[i][j][r] = act == ND_ACT_SOFTPLUS ? nd_softplus(u) : nd_act(u, act);
+            }
+    if (MODE == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int nf = tn * CG_F + wn * 4 + i;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int mf = tm * CG_F + wm * 4 + j;
+                if (nf < nfr && mf < mfr) {
+                    const int n0 = nf * 16 + 4 * g, m = mf * 16 + li;
+                    if (d.out_packed) {
+                        f32x4 v = acc[i][j];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) if (n0 + r >= N) v[r] = 0.f;
+                        *(__attribute__((address_space(1))) f32x4*)(d.out + ((size_t)mf * nfr + nf) * 256 + lane * 4) = v;
+                    } else if (m < M) {
+                        float* p = d.out + (size_t)m * N + n0;
+                        if (n0 + 3 < N && (N & 3) == 0) *(__attribute__((address_space(1))) f32x4*)p = acc[i][j];
+                        else {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) if (n0 + r < N) p[r] = acc[i][j][r];
+                        }
+                    }
+                }
+            }
+        }
+    } else {
+        const int C = d.C;
+        for (int c = 0; c < C; ++c) {
+            float pw[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = (tn * CG_F + wn * 4 + i) * 16 + 4 * g + r;
+                    pw[i][r] = n < N ? nd_ldg(d.pw + (size_t)c * N + n) : 0.0f;
+                }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float s = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) s += pw[i][r] * acc[i][j][r];
+                s += __shfl_xor(s, 16, 64);
+                s += __shfl_xor(s, 32, 64);
+                const int m = (tm * CG_F + wm * 4 + j) * 16 + li;
+                if (g == 0 && m < M) *(__attribute__((address_space(1))) float*)(d.part + ((size_t)m * C + c) * ntl + tn * 2 + wn) = s;
+            }
+        }
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_cond_gemm(SkinnyDesc d0, const SkinnyDesc* __restrict__ table, int M, int t, int TM, int TN,
+                                                   int n_full, int split, float* __restrict__ ws) {
+    // ONE LDS object (a second one beside an LDS-DMA target can make hipcc drain vmcnt before every ds_read)
+    __shared__ __attribute__((aligned(16))) float lds[2][2 * CG_F][256];      // 2 slots x (8 W + 8 x fragments) x 1 KiB = 32 KiB
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave >> 1, wm = wave & 1;            // this wave's 64 x 64 sub-tile
+    const CondGemmTile tl = cg_decode(blockIdx.x, n_full, split, TM, TN);
+    const SkinnyDesc d = table ? table[tl.member] : d0;
+    const int K = __builtin_amdgcn_readfirstlane(d.K), N = __builtin_amdgcn_readfirstlane(d.N);     // uniform: keeps the loop scalar
+    const int nch = K >> 4, nfr = (N + 15) >> 4, mfr = (M + 15) >> 4;
+    const int c0 = tl.slab < 0 ? 0 : (int)((long)tl.slab * nch / split);
+    const int c1 = tl.slab < 0 ? nch : (int)((long)(tl.slab + 1) * nch / split);
+    const int nk = c1 - c0;
+
+    // staging: wave w brings fragments 4w .. 4w+3 of a slot (waves 0,1: the tile's 8 W fragments; waves 2,3: its 8 x fragments);
+    // fragment indices past the matrix edge are clamped (their products are never stored)
+    const float* src[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        const int idx = wave * 4 + f;
+        src[f] = idx < CG_F ? d.w + ((size_t)min(tl.tn * CG_F + idx, nfr - 1) * nch + c0) * 256
+                            : d.x + ((size_t)min(tl.tm * CG_F + idx - CG_F, mfr - 1) * nch + c0) * 256;
+    }
+    const int lane4 = lane * 4;
+#define CG_STAGE(slot, step)                                                                                              \
+    {                                                                                                                     \
+        _Pragma("unroll") for (int f = 0; f < 4; ++f)                                                                     \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[f] + (size_t)(step) * 256 + lane4), \
+                                             (__attribute__((address_space(3))) void*)&lds[slot][wave * 4 + f][0], 16, 0, 0);       \
+    }
+#define CG_READ(FW, FX, slot)                                                                                             \
+    {                                                                                                                     \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) FW[i] = *reinterpret_cast<const f32x4*>(&lds[slot][wn * 4 + i][lane4]);        \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) FX[j] = *reinterpret_cast<const f32x4*>(&lds[slot][CG_F + wm * 4 + j][lane4]); \
+    }
+    // one k-quad of a step: 16 independent accumulators (dependent latency 40 > issue interval 32 cycles)
+#define CG_MMA_Q(FW, FX, q)                                                                                               \
+    {                                                                                                                     \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                     \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                 \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(FW[i][q], FX[j][q], acc[i][j], 0, 0, 0);                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                                \
+    }
+    // own LDS-DMA landed + own fragment reads done, then everybody's
+#define CG_SYNC()                                                                                                         \
+    {                                                                                                                     \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                       \
+        __builtin_amdgcn_s_barrier();                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                                \
+    }
+    // One step: the matrix pipe restarts right behind the barrier; the refill of the slot released by that barrier and the
+    // fragment reads of the next step are issued between the k-quads, so neither is waited for before 1024+ MFMA cycles.
+#define CG_STEP(CW, CX, NW, NX, cur_slot, nxt_slot, refill_step)                                                          \
+    {                                                                                                                     \
+        CG_SYNC()                                                                                                         \
+        CG_MMA_Q(CW, CX, 0)                                                                                               \
+        CG_STAGE(cur_slot, refill_step)                                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                                                \
+        CG_MMA_Q(CW, CX, 1)                                                                                               \
+        CG_READ(NW, NX, nxt_slot)                                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                                \
+        CG_MMA_Q(CW, CX, 2)                                                                                               \
+        CG_MMA_Q(CW, CX, 3)                                                                                               \
+    }
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 wA[4], xA[4], wB[4], xB[4];
+
+    // prologue: step 0 -> slot 0 and into set A, step 1 -> slot 1
+    CG_STAGE(0, 0)
+    CG_SYNC()
+    CG_READ(wA, xA, 0)
+    CG_STAGE(1, min(1, nk - 1))
+    __builtin_amdgcn_sched_barrier(0);
+    int s = 0;
+    for (; s + 2 <= nk; s += 2) {
+        // WRONG ORDER GUARD: the refill of slot 0 (step s+2) may only start once every wave has read step s out of it: the
+        // reads were issued before this step's barrier (prologue / previous step) and waited for in CG_SYNC
+        CG_STEP(wA, xA, wB, xB, 0, 1, min(s + 2, nk - 1))
+        CG_STEP(wB, xB, wA, xA, 1, 0, min(s + 3, nk - 1))
+    }
+    if (s < nk) {                                     // odd step count: the last step sits in set A
+        CG_MMA_Q(wA, xA, 0) CG_MMA_Q(wA, xA, 1) CG_MMA_Q(wA, xA, 2) CG_MMA_Q(wA, xA, 3)
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup's use of its LDS
+#undef CG_STAGE
+#undef CG_READ
+#undef CG_MMA_Q
+#undef CG_STEP
+#undef CG_SYNC
+
+    if (tl.slab >= 0) {
+        float* pt = ws + ((size_t)tl.rem_index * split + tl.slab) * (CG_T * CG_T) + (size_t)wave * 16 * 256;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) *(__attribute__((address_space(1))) f32x4*)(pt + (i * 4 + j) * 256 + lane4) = acc[i][j];
+        return;
+    }
+    cg_epilogue<MODE>(acc, d, M, t, tl.tm, tl.tn, wn, wm, lane, 2 * TN);
+}
+
+// Finishes the k-split tiles: accumulators = sum of the slabs in slab order, then the same epilogue.
+template <int MODE>
+__global__ __launch_bounds__(256) void k_cond_gemm_fixup(SkinnyDesc d0, const SkinnyDesc* __restrict__ table, int M, int t, int TM,
+                                                         int TN, int n_full, int split, const float* __restrict__ ws) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave >> 1, wm = wave & 1;
+    const int bid = n_full + blockIdx.x, per = TM * TN;
+    const int member = bid / per, r2 = bid - member * per, tn = r2 / TM, tm = r2 - tn * TM;
+    const SkinnyDesc d = table ? table[member] : d0;
+    const float* pt = ws + (size_t)blockIdx.x * split * (CG_T * CG_T) + (size_t)wave * 16 * 256 + lane * 4;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = *(const __attribute__((address_space(1))) f32x4*)(pt + (i * 4 + j) * 256);
+    for (int k = 1; k < split; ++k)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] += *(const __attribute__((address_space(1))) f32x4*)(pt + (size_t)k * (CG_T * CG_T) + (i * 4 + j) * 256);
+    cg_epilogue<MODE>(acc, d, M, t, tm, tn, wn, wm, lane, 2 * TN);
+}
+
+void* nd_cond_gemm_kernel(int mode) { return mode == 1 ? (void*)k_cond_gemm<1> : (void*)k_cond_gemm<0>; }
+void* nd_cond_gemm_fixup_kernel(int mode) { return mode == 1 ? (void*)k_cond_gemm_fixup<1> : (void*)k_cond_gemm_fixup<0>; }
+
+hipError_t nd_launch_cond_gemm(int mode, const CondGemmPlan& p, SkinnyDesc d0, const SkinnyDesc* table, int M, int t, float* ws,
+                               hipStream_t st) {
+    int TM = p.TM, TN = p.TN, n_full = p.n_full, split = p.split;
+    void* args[] = {&d0, &table, &M, &t, &TM, &TN, &n_full, &split, &ws};
+    hipError_t e = hipLaunchKernel(nd_cond_gemm_kernel(mode), dim3((unsigned)(p.n_full + p.rem * p.split)), dim3(256), args, 0, st);
+    if (e != hipSuccess || p.rem == 0) return e;
+    return hipLaunchKernel(nd_cond_gemm_fixup_kernel(mode), dim3((unsigned)p.rem), dim3(256), args, 0, st);
+}

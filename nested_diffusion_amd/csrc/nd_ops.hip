@@ -1,6 +1,7 @@
 // nd_ops.hip -- standalone operators: skinny Linear (mapping MLP), row softmax, ensemble aggregation.
 // gfx950 only.
 #include "nd_common.hpp"
+#include "nd_cond_gemm.hpp"
 #include "../../include/nested_diffusion.h"
 
 int nd_set_err(int code, const char* fmt, ...);
@@ -40,6 +41,7 @@ extern "C" size_t nd_linear_workspace_bytes(int M, int K, int N, int dtype) {
     const int half = dtype == ND_DTYPE_F16;
     size_t bytes = nd_packed_bytes_dt(M, K, half) + 256;
     if (nd_use_splitk(K)) bytes += nd_splitk_part_floats(M, K, N, 1, half) * sizeof(float);
+    else bytes += nd_cond_gemm_plan(K, N, M, 1, half).ws_bytes;      // k-slab accumulators of the large-M kernel's split tail
     return bytes + 256;
 }
 
@@ -68,7 +70,9 @@ extern "C" int nd_linear(const float* x, const void* wpk, const float* scale, co
         hipLaunchKernelGGL(k_splitk_epilogue, dim3((unsigned)((q + 255) / 256)), dim3(256), 0, st, se, (const SplitKEpiDesc*)nullptr, M, L.S);
     } else {
         SkinnyDesc d{xpk, wf, scale, shift, out, nullptr, nullptr, K, N, 0, act, 0};
-        HIP_CHECK(nd_launch_skinny(nd_skinny_launch<0>(K, N, M, 1, half), d, nullptr, 1, M, 0, st));
+        const CondGemmPlan tp = nd_cond_gemm_plan(K, N, M, 1, half);
+        if (tp.use_tile) HIP_CHECK(nd_launch_cond_gemm(0, tp, d, nullptr, M, 0, part, st));      // more than 128 rows: LDS-tiled
+        else HIP_CHECK(nd_launch_skinny(nd_skinny_launch<0>(K, N, M, 1, half), d, nullptr, 1, M, 0, st));
     }
     HIP_CHECK(hipGetLastError());
     return ND_OK;
@@ -87,6 +91,19 @@ extern "C" int nd_skinny_plan(int K, int N, int M, int n_members, int dtype, int
     out6[3] = (nfr + wpm - 1) / wpm;        // fragment slots per workgroup (the kernel's NF)
     out6[4] = L.cps;                        // k-chunks per slab
     out6[5] = (int)L.block.x;
+    return ND_OK;
+}
+
+// Which kernel a ConditionalLinear block of the sampler (K = N = F) runs at M = B*mc rows, and its tile plan.
+extern "C" int nd_step_plan(int F, int M, int n_members, int dtype, int* out8) {
+    if (!out8) return nd_set_err(ND_ERR_ARG, "out8 is NULL");
+    if (bad_dtype(dtype) || M < 1 || n_members < 1 || F < kmul(dtype) || (F % kmul(dtype))) return nd_set_err(ND_ERR_ARG, "bad shape / dtype");
+    const CondGemmPlan p = nd_cond_gemm_plan(F, F, M, n_members, dtype == ND_DTYPE_F16);
+    out8[0] = p.use_tile;                              // 0: k_skinny (weight streaming), 1: k_cond_gemm (LDS-tiled)
+    out8[1] = p.n_full + p.rem * p.split;              // workgroups of the tiled launch
+    out8[2] = p.n_full; out8[3] = p.rem; out8[4] = p.split;
+    out8[5] = p.use_tile ? p.ntl : (F + 15) / 16;      // partial sums per (row, class) left for the step head
+    out8[6] = p.TM; out8[7] = p.TN;
     return ND_OK;
 }
 

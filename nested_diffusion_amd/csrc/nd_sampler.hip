@@ -6,6 +6,7 @@
 //   diffusion/diffusion_utils.py:54-111    p_sample / p_sample_t_1to0
 //   diffusion/latent_model.py:93-105,169-184  ConditionalLinear / ConditionalModel.forward
 #include "nd_common.hpp"
+#include "nd_cond_gemm.hpp"
 #include "../../include/nested_diffusion.h"
 
 #include <map>
@@ -343,6 +344,7 @@ struct nd_handle_s {
     SplitKEpiDesc* spke_dev = nullptr;     // [K]
     float *alphas = nullptr, *omabs = nullptr;
     float* xpack = nullptr;                // frag16 [maxB][D] image batch shared by all members
+    float* tile_ws = nullptr;              // k-slab accumulators of k_cond_gemm's split tail (large-M steps only)
     int sched_T = 0;
     int NT = 0, S0 = 0;
     bool enc_splitk = false;
@@ -383,6 +385,7 @@ static void carve(nd_handle_s* h, char* base, size_t* total) {
     h->alphas = cv.take<float>(T);
     h->omabs = cv.take<float>(T);
     h->xpack = cv.take<float>(pB * D);
+    h->tile_ws = cv.take<float>(nd_cond_gemm_wanted((int)mM, h->half) ? (size_t)CG_MAX_SLABS * CG_T * CG_T : 1);
     for (size_t k = 0; k < K; ++k) {
         MemberHost& m = h->members[k];
         m.sc0 = cv.take<float>(H); m.sh0 = cv.take<float>(H);
@@ -561,6 +564,23 @@ static hipError_t launch_skinny(const SkinnyDesc* table, int K, int N, int M, in
     return nd_launch_skinny(nd_skinny_launch<MODE>(K, N, M, nm, half), SkinnyDesc{}, table, nm, M, t, st);
 }
 
+// One ConditionalLinear block (MODE 0: lin2, MODE 1: lin3 + lin4 projection) for nm members: the weight-streaming kernel for
+// small row counts, the LDS-tiled kernel above 128 rows (nd_cond_gemm.hpp).  Returns the partial-sum count per (row, class)
+// the MODE 1 form leaves in epart.
+static int step_partials(const nd_handle_s* h, int M) {
+    const int F = h->cfg.feature_dim;
+    const CondGemmPlan p = nd_cond_gemm_plan(F, F, M, 1, h->half);
+    return p.use_tile ? p.ntl : h->NT;
+}
+
+template <int MODE>
+static hipError_t launch_step_block(nd_handle_s* h, const SkinnyDesc* table, int M, int t, int nm, hipStream_t st) {
+    const int F = h->cfg.feature_dim;
+    const CondGemmPlan p = nd_cond_gemm_plan(F, F, M, nm, h->half);
+    if (p.use_tile) return nd_launch_cond_gemm(MODE, p, SkinnyDesc{}, table, M, t, h->tile_ws, st);
+    return launch_skinny<MODE>(table, F, F, M, t, nm, h->half, st);
+}
+
 extern "C" int nd_encode(nd_handle h, int m0, int nm, const float* x_dev, int B, void* stream) {
     int rc = check_range(h, m0, nm);
     if (rc != ND_OK) return rc;
@@ -642,15 +662,15 @@ static int single_eval(nd_handle_s* h, int member, StepIO io, int t, int final_m
     const int K = c.n_members, F = c.feature_dim, C = c.y_dim, M = B * mc;
     {
         const MemberDev* mdev = h->members_dev + member;
-        int mode = ND_HEAD_GIVEN, istep = 0, tprev = 0, tt = t, Bv = B, Mv = M, maxM = c.max_rows, Fv = F, NT = h->NT, Tn = c.n_steps;
+        int mode = ND_HEAD_GIVEN, istep = 0, tprev = 0, tt = t, Bv = B, Mv = M, maxM = c.max_rows, Fv = F, NT = step_partials(h, M), Tn = c.n_steps;
         void* ah[] = {&mdev, &io, &mode, &istep, &tprev, &tt, &Bv, &Mv, &maxM, &Fv, &NT, &Tn};
         HIP_CHECK(hipLaunchKernel(head_fn(C), dim3((F + 1023) / 1024, M, 1), dim3(256), ah, 0, st));
     }
-    HIP_CHECK(launch_skinny<0>(h->descs_dev + (size_t)L_LIN2 * K + member, F, F, M, t, 1, h->half, st));
-    HIP_CHECK(launch_skinny<1>(h->descs_dev + (size_t)L_LIN3 * K + member, F, F, M, t, 1, h->half, st));
+    HIP_CHECK(launch_step_block<0>(h, h->descs_dev + (size_t)L_LIN2 * K + member, M, t, 1, st));
+    HIP_CHECK(launch_step_block<1>(h, h->descs_dev + (size_t)L_LIN3 * K + member, M, t, 1, st));
     {
         const MemberDev* mdev = h->members_dev + member;
-        int fm = final_mode, tt = t, Bv = B, Mv = M, maxM = c.max_rows, NT = h->NT, Tn = c.n_steps;
+        int fm = final_mode, tt = t, Bv = B, Mv = M, maxM = c.max_rows, NT = step_partials(h, M), Tn = c.n_steps;
         size_t ems = 0;
         void* af[] = {&mdev, &io, &fm, &tt, &Bv, &Mv, &maxM, &NT, &Tn, &out, &ems};
         HIP_CHECK(hipLaunchKernel(final_fn(C), dim3(M, 1, 1), dim3(64), af, 0, st));
@@ -718,7 +738,7 @@ struct Emitter {
 
 static hipError_t emit_loop(nd_handle_s* h, Emitter& em, int m0, int nm, StepIO io, int B, int mc, int T) {
     const nd_config& c = h->cfg;
-    int K = c.n_members, F = c.feature_dim, C = c.y_dim, M = B * mc, maxM = c.max_rows, NT = h->NT, Tn = T;
+    int K = c.n_members, F = c.feature_dim, C = c.y_dim, M = B * mc, maxM = c.max_rows, NT = step_partials(h, M), Tn = T;
     const MemberDev* mdev = h->members_dev + m0;
     const SkinnyDesc* t2 = h->descs_dev + (size_t)L_LIN2 * K + m0;
     const SkinnyDesc* t3 = h->descs_dev + (size_t)L_LIN3 * K + m0;
@@ -726,6 +746,10 @@ static hipError_t emit_loop(nd_handle_s* h, Emitter& em, int m0, int nm, StepIO 
     const dim3 ghead((F + 1023) / 1024, M, nm);
     const SkinnyLaunch L2 = nd_skinny_launch<0>(F, F, M, nm, h->half), L3 = nd_skinny_launch<1>(F, F, M, nm, h->half);
     int cps2 = L2.cps, cps3 = L3.cps;
+    // more than 128 rows: the LDS-tiled kernel (+ its fixup for the k-split tail) takes the place of each k_skinny node
+    CondGemmPlan tp = nd_cond_gemm_plan(F, F, M, nm, h->half);
+    float* tws = h->tile_ws;
+    const dim3 tgrid((unsigned)(tp.n_full + tp.rem * tp.split)), tfix((unsigned)tp.rem);
     // probes: up to 8 steps spread over the loop (never step 0: its head is the cheap INIT form)
     const int want = h->profiling ? (T - 1 < 8 ? T - 1 : 8) : 0;
     const int stride = want > 0 ? (T - 1) / want : 0;
@@ -744,11 +768,21 @@ static hipError_t emit_loop(nd_handle_s* h, Emitter& em, int m0, int nm, StepIO 
         void* ah[] = {&mdev, &io, &mode, &istep, &t_prev, &t, &B, &M, &maxM, &F, &NT, &Tn};
         em.emit(head_fn(C), ghead, dim3(256), ah);
         if (probe) em.record(ev[1]);
-        void* a2[] = {&d0, &t2, &nm, &M, &t, &cps2};
-        em.emit(L2.fn, L2.grid, L2.block, a2);
-        if (probe) em.record(ev[2]);
-        void* a3[] = {&d0, &t3, &nm, &M, &t, &cps3};
-        em.emit(L3.fn, L3.grid, L3.block, a3);
+        if (tp.use_tile) {
+            void* a2[] = {&d0, &t2, &M, &t, &tp.TM, &tp.TN, &tp.n_full, &tp.split, &tws};
+            em.emit(nd_cond_gemm_kernel(0), tgrid, dim3(256), a2);
+            if (tp.rem > 0) em.emit(nd_cond_gemm_fixup_kernel(0), tfix, dim3(256), a2);
+            if (probe) em.record(ev[2]);
+            void* a3[] = {&d0, &t3, &M, &t, &tp.TM, &tp.TN, &tp.n_full, &tp.split, &tws};
+            em.emit(nd_cond_gemm_kernel(1), tgrid, dim3(256), a3);
+            if (tp.rem > 0) em.emit(nd_cond_gemm_fixup_kernel(1), tfix, dim3(256), a3);
+        } else {
+            void* a2[] = {&d0, &t2, &nm, &M, &t, &cps2};
+            em.emit(L2.fn, L2.grid, L2.block, a2);
+            if (probe) em.record(ev[2]);
+            void* a3[] = {&d0, &t3, &nm, &M, &t, &cps3};
+            em.emit(L3.fn, L3.grid, L3.block, a3);
+        }
         if (probe) { em.record(ev[3]); em.record(ev[4]); ++probed; }     // e3 -> e4 brackets nothing: the cost of a record node itself
     }
     h->probe_steps = probed;

@@ -149,6 +149,17 @@ class EnsembleEngine:
         self.probe_overhead_us = float(us[3])
         return float(us[0]), float(us[1]), float(us[2]), int(n.value)
 
+    def step_plan(self, M: int, n_members: Optional[int] = None) -> Dict[str, object]:
+        """Which kernel the lin2 / lin3 blocks of a step run at M = B*mc rows (host-side plan, no launch)."""
+        out = (C.c_int * 8)()
+        n_members = self.K if n_members is None else n_members
+        check(self.lib.nd_step_plan(self.F, int(M), int(n_members), self.dtype, out), "nd_step_plan")
+        tile = bool(out[0])
+        name = ("k_cond_gemm<{0,1}> (LDS-tiled 128x128 f32-MFMA ConditionalLinear blocks, K members per launch)" if tile else
+                "k_skinny<MT,NF,4,U,{0,1}> (weight-streaming lin2 / lin3+lin4 ConditionalLinear blocks, K members per launch)")
+        return {"kernel": "k_cond_gemm" if tile else "k_skinny", "name": name, "workgroups": out[1], "whole_tiles": out[2],
+                "remainder_tiles": out[3], "split": out[4], "partials": out[5], "TM": out[6], "TN": out[7]}
+
     def static_buffers(self, n_members: int, B: int, mc: int, T: int, seq: bool) -> Dict[str, torch.Tensor]:
         """Fixed-address I/O tensors so the hipGraph of a (members, B, mc, T) shape is built once."""
         key = (n_members, B, mc, T, seq)

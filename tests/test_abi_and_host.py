@@ -213,6 +213,37 @@ def test_launch_plans_on_the_host():
     assert lib.nd_gemm_workspace_bytes(6272, 768, 768, 1) > 0 and lib.nd_gemm_workspace_bytes(6272, 48, 768, 1) == 0   # fp16: K % 32
 
 
+def test_step_block_dispatch_threshold_and_tile_plan():
+    """nd_step_plan (host only): which kernel a ConditionalLinear block runs at M = B*mc rows.  Up to 128 rows the
+    weight-streaming k_skinny (one or two 64-row passes), above that the LDS-tiled k_cond_gemm; fp16 operands always stream.
+    The reference's own points: mc = 20 x B = 32 / 70 (classification_train_separately.py:770-771, configs/chest_x_ray.yml:66)."""
+    import ctypes as C
+    from nested_diffusion_amd import _lib
+    lib = _lib.load()
+
+    def plan(F, M, nm, dtype=0):
+        out = (C.c_int * 8)()
+        assert lib.nd_step_plan(F, M, nm, dtype, out) == 0, lib.nd_last_error()
+        return dict(zip(("tile", "wgs", "whole", "rem", "split", "partials", "TM", "TN"), out))
+
+    for M in (1, 32, 64, 70, 128):
+        p = plan(4096, M, 5)
+        assert p["tile"] == 0 and p["partials"] == 256, (M, p)              # one partial per 16 columns
+    p = plan(4096, 129, 5)
+    assert p["tile"] == 1 and p["TM"] == 2 and p["TN"] == 32 and p["partials"] == 64
+    p = plan(4096, 640, 5)                                                      # mc = 20, B = 32, K = 5: 5 x 5 x 32 tiles
+    assert (p["tile"], p["TM"], p["TN"], p["whole"], p["rem"], p["split"]) == (1, 5, 32, 768, 32, 8)
+    assert p["wgs"] == 768 + 32 * 8 and p["rem"] * p["split"] <= 512            # slab workspace bound (32 MB)
+    p = plan(4096, 1400, 5)                                                     # mc = 20, B = 70: 11 x 32 x 5 = 1760 tiles
+    assert p["tile"] == 1 and p["TM"] == 11 and p["whole"] + p["rem"] == 1760
+    if p["rem"]:
+        assert p["rem"] * p["split"] <= 512
+    assert plan(4096, 1400, 5, 1)["tile"] == 0                                  # fp16 operands: streaming kernel
+    assert plan(96, 144, 2)["tile"] == 1 and plan(96, 144, 2)["TN"] == 1        # tiny feature_dim: one ragged column tile
+    out = (C.c_int * 8)()
+    assert lib.nd_step_plan(4096, 0, 5, 0, out) != 0 and lib.nd_step_plan(40, 32, 1, 0, out) != 0
+
+
 def test_step_gemm_loops_keep_counted_waits():
     """ISA check (no GPU): every software-pipelined k_skinny loop must wait with a counted vmcnt and contain no flat_load --
     a pending flat load (pointer read out of a descriptor table without an address-space cast) or an uncountable load before

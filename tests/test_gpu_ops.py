@@ -36,6 +36,24 @@ def test_linear_fused_skinny(M, K, N, act):
     _close(out2, (x.double() @ w.double().T).float(), 2e-5)
 
 
+@pytest.mark.parametrize("M,K,N,act", [(129, 64, 16, None), (640, 4096, 4096, "softplus"), (1400, 4096, 2048, "relu"), (200, 160, 130, "gelu"),
+                                       (257, 48, 7, None), (1000, 1024, 1000, "relu"), (300, 16, 300, None), (2048, 512, 136, "softplus")])
+def test_linear_large_m_tiled(M, K, N, act):
+    """More than 128 rows: nd_linear runs the LDS-tiled k_cond_gemm (MODE 0, row-major output), with ragged row / column
+    tiles, N not a multiple of 4, a single k-step (K = 16), odd k-step counts, and the k-split tail + fixup."""
+    from nested_diffusion_amd import ops
+    g = torch.Generator().manual_seed(M * 7 + N)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    s = torch.rand(N, generator=g) + 0.5
+    out = ops.linear(x.cuda(), w.cuda(), b.cuda(), act=act, scale=s.cuda())
+    ref = s * (x.double() @ w.double().T).float() + b
+    ref = {None: lambda v: v, "softplus": F.softplus, "relu": F.relu, "gelu": F.gelu}[act](ref)
+    _close(out, ref, 2e-5)
+    assert torch.equal(ops.linear(x.cuda(), w.cuda(), b.cuda(), act=act, scale=s.cuda()), out)     # reproducible
+
+
 @pytest.mark.parametrize("M,K,N", [(4, 16384, 64), (32, 150528, 256), (2, 32768 + 16, 130), (33, 20000 - 16 * 2, 128)])
 def test_linear_splitk(M, K, N):
     from nested_diffusion_amd import ops

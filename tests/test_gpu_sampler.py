@@ -242,6 +242,53 @@ def test_large_m_row_groups(B, mc, F_, C_):
     assert (eps - ref).abs().max() < 5e-5 * max(1.0, ref.abs().max())
 
 
+@pytest.mark.parametrize("B,mc,K", [(32, 20, 5), (70, 20, 2), (33, 5, 1)])
+def test_reference_default_mc20_rows_at_feature_dim_4096(B, mc, K):
+    """The reference's own operating point: mc_trials = 20 (classification_train_separately.py:770-771) x batch 32 / 70
+    (configs/chest_x_ray.yml:66) -> M = 640 / 1400 rows per member through lin2 / lin3 at F = 4096 -- the LDS-tiled
+    k_cond_gemm (M > 128), incl. its k-split tail + fixup (K = 5, M = 640: 800 tiles = 768 whole + 32 cut 8 ways) and a ragged
+    last row tile (M = 165).  y_0 of every (member, trial) vs the oracle; graph == eager bitwise."""
+    from nested_diffusion_amd.engine import EnsembleEngine
+    D, H, F_, C_, T = 64, 64, 4096, 2, 3
+    ps = [ref_cpu.init_cond_model_params(D, H, F_, C_, T, True, seed=300 + k) for k in range(K)]
+    eng = EnsembleEngine(C_, D, H, F_, T, n_members=K, max_batch=B, max_rows=B * mc)
+    plan = eng.step_plan(B * mc)
+    assert plan["kernel"] == "k_cond_gemm"
+    if (B, mc, K) == (32, 20, 5):
+        assert (plan["whole_tiles"], plan["remainder_tiles"], plan["split"]) == (768, 32, 8)
+    for k, p in enumerate(ps):
+        eng.load_member(k, p)
+    alphas, omabs = ref_cpu.schedule_tables("linear", T, 1e-4, 0.02)
+    eng.set_schedule(alphas, omabs)
+    g = torch.Generator().manual_seed(14)
+    x = torch.rand(B, D, generator=g)
+    yhat = torch.softmax(torch.randn(K, B, C_, generator=g), -1)
+    noise = torch.randn(K, T, B * mc, C_, generator=g)
+    eng.encode(x)
+    y0 = eng.sample(yhat.cuda(), yhat.cuda(), noise.cuda(), mc=mc).cpu()
+    assert torch.equal(eng.sample(yhat.cuda(), yhat.cuda(), noise.cuda(), mc=mc, use_graph=False).cpu(), y0)
+    worst = 0.0
+    for k, p in enumerate(ps):
+        xe = ref_cpu.encoder_x(p, x)
+        # all mc trials of a member at once on the CPU: rows = trial * B + image, as the engine lays them out
+        cur = noise[k, 0] + yhat[k].repeat(mc, 1)
+        ymean, yh, xer = yhat[k].repeat(mc, 1), yhat[k].repeat(mc, 1), xe.repeat(mc, 1)
+        for i, t in enumerate(reversed(range(1, T)), start=1):
+            eps = ref_cpu.trunk(p, xer, cur, torch.tensor([t]), yh)
+            cur = ref_cpu.p_sample_given_eps(cur, ymean, eps, t, alphas, omabs, noise[k, i])
+        eps = ref_cpu.trunk(p, xer, cur, torch.tensor([0]), yh)
+        ref = ref_cpu.p_sample_t_1to0_given_eps(cur, ymean, eps, omabs)
+        err = (y0[k] - ref).abs().max().item() / max(1.0, ref.abs().max().item())
+        worst = max(worst, err)
+        assert err < 5e-5, (k, err)
+    # one eps_theta evaluation (nd_eps_theta: eager launches of the same kernels)
+    yy = torch.randn(B * mc, C_, generator=g)
+    eps = eng.eps_theta(K - 1, yy, yhat[K - 1], 1, mc=mc).cpu()
+    ref = ref_cpu.trunk(ps[-1], ref_cpu.encoder_x(ps[-1], x).repeat(mc, 1), yy, torch.tensor([1]), yhat[K - 1].repeat(mc, 1))
+    assert (eps - ref).abs().max() < 5e-5 * max(1.0, ref.abs().max())
+    print(f"M={B * mc} K={K}: max rel y0 err {worst:.2e}, plan {plan}")
+
+
 @pytest.mark.parametrize("T,B,C_", [(1, 2, 2), (2, 1, 2), (3, 5, 1), (4, 1, 5)])
 def test_edge_sizes(T, B, C_):
     """Smallest loops (T = 1: no reverse step, only the t = 0 reparameterisation), single image, one and five classes."""
