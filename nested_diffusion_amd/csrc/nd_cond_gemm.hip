@@ -109,11 +109,19 @@ __device__ __forceinline__ void cg_epilogue(f32x4 (&acc)[4][4], const SkinnyDesc
     }
 }
 
-template <int MODE>
+__device__ __forceinline__ const float* cg_uniform_ptr(const float* p) {
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (const float*)(((unsigned long long)hi << 32) | lo);
+}
+
+// NS = LDS slots of the staging ring: the LDS-DMA of step j + NS is issued during step j, so a step's operands have NS - 1
+// whole steps to land (NS = 2: 32 KiB of LDS per workgroup, NS = 3: 48 KiB).
+template <int MODE, int NS>
 __global__ __launch_bounds__(256) void k_cond_gemm(SkinnyDesc d0, const SkinnyDesc* __restrict__ table, int M, int t, int TM, int TN,
                                                    int n_full, int split, float* __restrict__ ws) {
     // ONE LDS object (a second one beside an LDS-DMA target can make hipcc drain vmcnt before every ds_read)
-    __shared__ __attribute__((aligned(16))) float lds[2][2 * CG_F][256];      // 2 slots x (8 W + 8 x fragments) x 1 KiB = 32 KiB
+    __shared__ __attribute__((aligned(16))) float lds[NS][2 * CG_F][256];     // NS slots x (8 W + 8 x fragments) x 1 KiB
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave >> 1, wm = wave & 1;            // this wave's 64 x 64 sub-tile
@@ -127,12 +135,15 @@ __global__ __launch_bounds__(256) void k_cond_gemm(SkinnyDesc d0, const SkinnyDe
 
     // staging: wave w brings fragments 4w .. 4w+3 of a slot (waves 0,1: the tile's 8 W fragments; waves 2,3: its 8 x fragments);
     // fragment indices past the matrix edge are clamped (their products are never stored)
+    // (operand bases made wave-uniform: the DMA address is then an SGPR pair + a constant per-lane offset, no VALU per piece)
+    const float* wbase = cg_uniform_ptr(d.w);
+    const float* xbase = cg_uniform_ptr(d.x);
     const float* src[4];
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
         const int idx = wave * 4 + f;
-        src[f] = idx < CG_F ? d.w + ((size_t)min(tl.tn * CG_F + idx, nfr - 1) * nch + c0) * 256
-                            : d.x + ((size_t)min(tl.tm * CG_F + idx - CG_F, mfr - 1) * nch + c0) * 256;
+        src[f] = idx < CG_F ? wbase + ((size_t)min(tl.tn * CG_F + idx, nfr - 1) * nch + c0) * 256
+                            : xbase + ((size_t)min(tl.tm * CG_F + idx - CG_F, mfr - 1) * nch + c0) * 256;
     }
     const int lane4 = lane * 4;
 #define CG_STAGE(slot, step)                                                                                              \
@@ -141,39 +152,24 @@ __global__ __launch_bounds__(256) void k_cond_gemm(SkinnyDesc d0, const SkinnyDe
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[f] + (size_t)(step) * 256 + lane4), \
                                              (__attribute__((address_space(3))) void*)&lds[slot][wave * 4 + f][0], 16, 0, 0);       \
     }
-#define CG_READ(FW, FX, slot)                                                                                             \
+#define CG_READ(set, slot)                                                                                                \
     {                                                                                                                     \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) FW[i] = *reinterpret_cast<const f32x4*>(&lds[slot][wn * 4 + i][lane4]);        \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j) FX[j] = *reinterpret_cast<const f32x4*>(&lds[slot][CG_F + wm * 4 + j][lane4]); \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) fw[set][i] = *reinterpret_cast<const f32x4*>(&lds[slot][wn * 4 + i][lane4]);        \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) fx[set][j] = *reinterpret_cast<const f32x4*>(&lds[slot][CG_F + wm * 4 + j][lane4]); \
     }
     // one k-quad of a step: 16 independent accumulators (dependent latency 40 > issue interval 32 cycles)
-#define CG_MMA_Q(FW, FX, q)                                                                                               \
+#define CG_MMA_Q(set, q)                                                                                                  \
     {                                                                                                                     \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                     \
             _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                 \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(FW[i][q], FX[j][q], acc[i][j], 0, 0, 0);                 \
-        __builtin_amdgcn_sched_barrier(0);                                                                                \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fw[set][i][q], fx[set][j][q], acc[i][j], 0, 0, 0);       \
     }
-    // own LDS-DMA landed + own fragment reads done, then everybody's
+    // all but the NS - 2 youngest steps' LDS-DMA of this wave landed (4 per step) + own fragment reads done, then everybody's
 #define CG_SYNC()                                                                                                         \
     {                                                                                                                     \
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                       \
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(4 * (NS - 2)) : "memory");                                    \
         __builtin_amdgcn_s_barrier();                                                                                     \
         __builtin_amdgcn_sched_barrier(0);                                                                                \
-    }
-    // One step: the matrix pipe restarts right behind the barrier; the refill of the slot released by that barrier and the
-    // fragment reads of the next step are issued between the k-quads, so neither is waited for before 1024+ MFMA cycles.
-#define CG_STEP(CW, CX, NW, NX, cur_slot, nxt_slot, refill_step)                                                          \
-    {                                                                                                                     \
-        CG_SYNC()                                                                                                         \
-        CG_MMA_Q(CW, CX, 0)                                                                                               \
-        CG_STAGE(cur_slot, refill_step)                                                                                   \
-        __builtin_amdgcn_sched_barrier(0);                                                                                \
-        CG_MMA_Q(CW, CX, 1)                                                                                               \
-        CG_READ(NW, NX, nxt_slot)                                                                                         \
-        __builtin_amdgcn_sched_barrier(0);                                                                                \
-        CG_MMA_Q(CW, CX, 2)                                                                                               \
-        CG_MMA_Q(CW, CX, 3)                                                                                               \
     }
 
     f32x4 acc[4][4];
@@ -181,29 +177,49 @@ __global__ __launch_bounds__(256) void k_cond_gemm(SkinnyDesc d0, const SkinnyDe
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 wA[4], xA[4], wB[4], xB[4];
+    f32x4 fw[2][4], fx[2][4];                          // two register sets, indexed by step parity (static after unrolling)
 
-    // prologue: step 0 -> slot 0 and into set A, step 1 -> slot 1
-    CG_STAGE(0, 0)
-    CG_SYNC()
-    CG_READ(wA, xA, 0)
-    CG_STAGE(1, min(1, nk - 1))
+    // prologue: steps 0 .. NS-1 -> slots 0 .. NS-1 (clamped past the end: valid data nobody reads), step 0 into set 0
+#pragma unroll
+    for (int u = 0; u < NS; ++u) CG_STAGE(u, min(u, nk - 1))
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (NS - 1)) : "memory");
+    __builtin_amdgcn_s_barrier();
+    CG_READ(0, 0)
     __builtin_amdgcn_sched_barrier(0);
-    int s = 0;
-    for (; s + 2 <= nk; s += 2) {
-        // WRONG ORDER GUARD: the refill of slot 0 (step s+2) may only start once every wave has read step s out of it: the
-        // reads were issued before this step's barrier (prologue / previous step) and waited for in CG_SYNC
-        CG_STEP(wA, xA, wB, xB, 0, 1, min(s + 2, nk - 1))
-        CG_STEP(wB, xB, wA, xA, 1, 0, min(s + 3, nk - 1))
-    }
-    if (s < nk) {                                     // odd step count: the last step sits in set A
-        CG_MMA_Q(wA, xA, 0) CG_MMA_Q(wA, xA, 1) CG_MMA_Q(wA, xA, 2) CG_MMA_Q(wA, xA, 3)
+    // Step j (register set j & 1, slot j % NS): the matrix pipe restarts right behind the barrier; the refill of the slot that
+    // barrier released (slot j % NS: its reads were issued in step j-1 and retired in this step's CG_SYNC) with step j + NS, and
+    // the fragment reads of step j + 1, are issued between the k-quads, so neither is waited for before 1024+ MFMA cycles.
+    constexpr int U = (NS % 2 == 0) ? NS : 2 * NS;     // unroll: slot and register-set indices are compile-time constants
+    for (int s = 0; s < nk; s += U) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (s + u < nk) {
+                CG_SYNC()
+                // one scheduling region: 4 LDS-DMA pieces (slot released by this barrier <- step j + NS), 8 fragment reads
+                // (step j + 1 -> the other register set) and the 64 MFMAs of step j; the group barriers below deal them out as
+                // 4 MFMAs : 1 memory instruction, MFMAs first, so every memory instruction issues in the shadow of running MFMAs
+                CG_STAGE(u % NS, min(s + u + NS, nk - 1))
+                CG_READ((u + 1) & 1, (u + 1) % NS)
+                CG_MMA_Q(u & 1, 0) CG_MMA_Q(u & 1, 1) CG_MMA_Q(u & 1, 2) CG_MMA_Q(u & 1, 3)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup's use of its LDS
 #undef CG_STAGE
 #undef CG_READ
 #undef CG_MMA_Q
-#undef CG_STEP
 #undef CG_SYNC
 
     if (tl.slab >= 0) {
@@ -217,21 +233,23 @@ __global__ __launch_bounds__(256) void k_cond_gemm(SkinnyDesc d0, const SkinnyDe
     cg_epilogue<MODE>(acc, d, M, t, tl.tm, tl.tn, wn, wm, lane, 2 * TN);
 }
 
-// Finishes the k-split tiles: accumulators = sum of the slabs in slab order, then the same epilogue.
+// Finishes the k-split tiles: accumulators = sum of the slabs in slab order, then the same epilogue.  One WAVE per workgroup
+// (a 64 x 64 sub-tile), 4 workgroups per tile: the kernel is a latency chain of slab reads, so it wants many small workgroups.
 template <int MODE>
-__global__ __launch_bounds__(256) void k_cond_gemm_fixup(SkinnyDesc d0, const SkinnyDesc* __restrict__ table, int M, int t, int TM,
-                                                         int TN, int n_full, int split, const float* __restrict__ ws) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+__global__ __launch_bounds__(64) void k_cond_gemm_fixup(SkinnyDesc d0, const SkinnyDesc* __restrict__ table, int M, int t, int TM,
+                                                        int TN, int n_full, int split, const float* __restrict__ ws) {
+    const int lane = threadIdx.x, wave = blockIdx.x & 3, ri = blockIdx.x >> 2;
     const int wn = wave >> 1, wm = wave & 1;
-    const int bid = n_full + blockIdx.x, per = TM * TN;
+    const int bid = n_full + ri, per = TM * TN;
     const int member = bid / per, r2 = bid - member * per, tn = r2 / TM, tm = r2 - tn * TM;
     const SkinnyDesc d = table ? table[member] : d0;
-    const float* pt = ws + (size_t)blockIdx.x * split * (CG_T * CG_T) + (size_t)wave * 16 * 256 + lane * 4;
+    const float* pt = ws + (size_t)ri * split * (CG_T * CG_T) + (size_t)wave * 16 * 256 + lane * 4;
     f32x4 acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = *(const __attribute__((address_space(1))) f32x4*)(pt + (i * 4 + j) * 256);
+#pragma unroll 2
     for (int k = 1; k < split; ++k)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -241,14 +259,21 @@ __global__ __launch_bounds__(256) void k_cond_gemm_fixup(SkinnyDesc d0, const Sk
     cg_epilogue<MODE>(acc, d, M, t, tm, tn, wn, wm, lane, 2 * TN);
 }
 
-void* nd_cond_gemm_kernel(int mode) { return mode == 1 ? (void*)k_cond_gemm<1> : (void*)k_cond_gemm<0>; }
+// Staging depth 3: 48 KiB of LDS and 160 VGPRs per workgroup, three workgroups resident per CU.  Measured at M = 640, K = 5
+// members (800 tiles): 811 / 796 us per launch (lin2 / lin3+lin4) = 132 / 135 TFLOP/s; one workgroup per CU with the same
+// code 842 us; before the 4 : 1 MFMA : memory interleave three per CU took 940 us (the co-resident waves' LDS-DMA issue stalled
+// each other's matrix pipe).  Steady state (tools/bench_cond_gemm.py, 1536 tiles): 230 us per round of 256 tiles against
+// 218 us of pure MFMA time = 95 %; the rest of a launch is ~35 us of ramp + the epilogues of the last resident tiles.
+#define CG_SLOTS 3
+size_t nd_cond_gemm_dynlds() { return 0; }
+void* nd_cond_gemm_kernel(int mode) { return mode == 1 ? (void*)k_cond_gemm<1, CG_SLOTS> : (void*)k_cond_gemm<0, CG_SLOTS>; }
 void* nd_cond_gemm_fixup_kernel(int mode) { return mode == 1 ? (void*)k_cond_gemm_fixup<1> : (void*)k_cond_gemm_fixup<0>; }
 
 hipError_t nd_launch_cond_gemm(int mode, const CondGemmPlan& p, SkinnyDesc d0, const SkinnyDesc* table, int M, int t, float* ws,
                                hipStream_t st) {
     int TM = p.TM, TN = p.TN, n_full = p.n_full, split = p.split;
     void* args[] = {&d0, &table, &M, &t, &TM, &TN, &n_full, &split, &ws};
-    hipError_t e = hipLaunchKernel(nd_cond_gemm_kernel(mode), dim3((unsigned)(p.n_full + p.rem * p.split)), dim3(256), args, 0, st);
+    hipError_t e = hipLaunchKernel(nd_cond_gemm_kernel(mode), dim3((unsigned)(p.n_full + p.rem * p.split)), dim3(256), args, nd_cond_gemm_dynlds(), st);
     if (e != hipSuccess || p.rem == 0) return e;
-    return hipLaunchKernel(nd_cond_gemm_fixup_kernel(mode), dim3((unsigned)p.rem), dim3(256), args, 0, st);
+    return hipLaunchKernel(nd_cond_gemm_fixup_kernel(mode), dim3((unsigned)p.rem * 4), dim3(64), args, 0, st);
 }

@@ -12,10 +12,11 @@
 // 1 KiB each.  Because frag16 stores a 16x16 block in the lane order the MFMA consumes, a block goes global -> LDS with ONE
 // global_load_lds_dwordx4 per wave (no VGPR round trip, no address arithmetic, no padding) and LDS -> registers with one
 // conflict-free ds_read_b128 per lane (lane l reads bytes 16 l .. 16 l + 15 of the block: a linear 1 KiB sweep).
-// Pipeline per K-step s (two LDS slots, two register sets, ONE barrier):
-//     wait own LDS-DMA of step s+1 + own LDS reads of step s  ->  barrier  ->  ds_read step s+1 (other register set)
-//     ->  issue LDS-DMA of step s+2 into the slot just released  ->  64 MFMAs of step s.
-// so the DMA has a whole step (2048 MFMA cycles) to land and the fragment reads fly under the MFMAs.
+// Pipeline per K-step j (ring of NS = 3 LDS slots, two register sets, ONE barrier per step):
+//     wait own LDS-DMA of step j+1 + own LDS reads of step j  ->  barrier  ->  { 64 MFMAs of step j, between them: the 4 LDS-DMA
+//     pieces of step j+3 into the slot the barrier released, and the 8 fragment reads of step j+1 into the other register set }
+// dealt out 4 MFMAs : 1 memory instruction (sched_group_barrier), so the matrix pipe restarts right behind the barrier and no
+// memory instruction is issued outside the shadow of running MFMAs; the DMA has two whole steps to land.
 //
 // Tiles of all members are one flat list (member, n-tile, m-tile: m fastest), dealt to the XCDs in contiguous runs so the
 // workgroups that share an XCD's L2 share W and x panels.  tiles % CUs != 0 would leave the last round partly empty:
@@ -74,7 +75,8 @@ static inline CondGemmPlan nd_cond_gemm_plan(int K, int N, int M, int nm, int ha
 // the 64 accumulator registers of a wave stay in the VGPR file (with AGPR accumulators hipcc re-sorts all 64 of them with
 // v_accvgpr moves once per loop trip), without touching the code generation of the other kernels.
 void* nd_cond_gemm_kernel(int mode);          // kernel handles (MODE 0 / 1 as k_skinny) for hipGraph kernel nodes; argument list:
-void* nd_cond_gemm_fixup_kernel(int mode);    //   (SkinnyDesc d0, const SkinnyDesc* table, int M, int t, int TM, int TN, int n_full, int split, float* ws)
+void* nd_cond_gemm_fixup_kernel(int mode);
+size_t nd_cond_gemm_dynlds();                 // dynamic LDS bytes of the launch (0: the staging ring is static)    //   (SkinnyDesc d0, const SkinnyDesc* table, int M, int t, int TM, int TN, int n_full, int split, float* ws)
 // d0 / table as nd_launch_skinny.  ws: >= plan.ws_bytes (may be null when plan.rem == 0).
 hipError_t nd_launch_cond_gemm(int mode, const CondGemmPlan& p, SkinnyDesc d0, const SkinnyDesc* table, int M, int t, float* ws,
                                hipStream_t st);

@@ -722,13 +722,13 @@ struct Emitter {
             last = node;
         }
     }
-    void emit(void* fn, dim3 grid, dim3 block, void** args) {
+    void emit(void* fn, dim3 grid, dim3 block, void** args, size_t lds = 0) {
         if (err != hipSuccess) return;
         if (!graph) {
-            err = hipLaunchKernel(fn, grid, block, args, 0, st);
+            err = hipLaunchKernel(fn, grid, block, args, lds, st);
         } else {
             hipKernelNodeParams p{};
-            p.func = fn; p.gridDim = grid; p.blockDim = block; p.sharedMemBytes = 0; p.kernelParams = args; p.extra = nullptr;
+            p.func = fn; p.gridDim = grid; p.blockDim = block; p.sharedMemBytes = (unsigned)lds; p.kernelParams = args; p.extra = nullptr;
             hipGraphNode_t node;
             err = hipGraphAddKernelNode(&node, graph, last ? &last : nullptr, last ? 1 : 0, &p);
             last = node;
@@ -749,7 +749,7 @@ static hipError_t emit_loop(nd_handle_s* h, Emitter& em, int m0, int nm, StepIO 
     // more than 128 rows: the LDS-tiled kernel (+ its fixup for the k-split tail) takes the place of each k_skinny node
     CondGemmPlan tp = nd_cond_gemm_plan(F, F, M, nm, h->half);
     float* tws = h->tile_ws;
-    const dim3 tgrid((unsigned)(tp.n_full + tp.rem * tp.split)), tfix((unsigned)tp.rem);
+    const dim3 tgrid((unsigned)(tp.n_full + tp.rem * tp.split)), tfix((unsigned)tp.rem * 4);
     // probes: up to 8 steps spread over the loop (never step 0: its head is the cheap INIT form)
     const int want = h->profiling ? (T - 1 < 8 ? T - 1 : 8) : 0;
     const int stride = want > 0 ? (T - 1) / want : 0;
@@ -770,12 +770,12 @@ static hipError_t emit_loop(nd_handle_s* h, Emitter& em, int m0, int nm, StepIO 
         if (probe) em.record(ev[1]);
         if (tp.use_tile) {
             void* a2[] = {&d0, &t2, &M, &t, &tp.TM, &tp.TN, &tp.n_full, &tp.split, &tws};
-            em.emit(nd_cond_gemm_kernel(0), tgrid, dim3(256), a2);
-            if (tp.rem > 0) em.emit(nd_cond_gemm_fixup_kernel(0), tfix, dim3(256), a2);
+            em.emit(nd_cond_gemm_kernel(0), tgrid, dim3(256), a2, nd_cond_gemm_dynlds());
+            if (tp.rem > 0) em.emit(nd_cond_gemm_fixup_kernel(0), tfix, dim3(64), a2);
             if (probe) em.record(ev[2]);
             void* a3[] = {&d0, &t3, &M, &t, &tp.TM, &tp.TN, &tp.n_full, &tp.split, &tws};
-            em.emit(nd_cond_gemm_kernel(1), tgrid, dim3(256), a3);
-            if (tp.rem > 0) em.emit(nd_cond_gemm_fixup_kernel(1), tfix, dim3(256), a3);
+            em.emit(nd_cond_gemm_kernel(1), tgrid, dim3(256), a3, nd_cond_gemm_dynlds());
+            if (tp.rem > 0) em.emit(nd_cond_gemm_fixup_kernel(1), tfix, dim3(64), a3);
         } else {
             void* a2[] = {&d0, &t2, &nm, &M, &t, &cps2};
             em.emit(L2.fn, L2.grid, L2.block, a2);
