@@ -703,189 +703,8 @@ static hipError_t launch_attention_lds(const float* qkv, float* out, int B, int 
     return hipGetLastError();
 }
 
-// RING form (the default fp32 kernel).  A workgroup is FOUR waves -- one per SIMD -- owning up to four 16-row query fragments
-// of one (image, head): ceil(NF/4) workgroups per head (NF = 13 at N = 196: 4 + 3 + 3 + 3 fragments), 1536 workgroups at
-// B = 32 x 12 heads, two resident per CU (56 KiB of LDS each).  K and V pass through a two-slot LDS ring as four tiles
-// K0, K1, V0, V1 of ceil(NF/2) key fragments, brought by LDS-DMA (global_load_lds_dwordx4: one 1 KiB piece = 4 key rows per wave
-// instruction, no VGPR round trip); V0 and V1 are fetched while the scores are computed, so only K0 is ever waited for:
-//     DMA K0, K1 | S[tile 0] = K0 q | DMA V0 -> slot 0 | S[tile 1] = K1 q | DMA V1 -> slot 1 | softmax | O += P V0 | O += P V1
-// The score fragments of all keys stay in registers, the softmax is the exact two-pass form (max, exp, sum, normalise) of
-// the kernels above: same arithmetic, same operand maps, bit-identical results.
-// LDS images are unpadded 256-byte rows (an LDS-DMA piece is written lane-linear).  K rows are stored with their 16-byte
-// chunks XOR-swizzled by (row & 15) -- applied on the DMA's per-lane SOURCE address and again on the read -- so the MFMA
-// operand read (16 key rows x one chunk column per ds_read_b128 lane group) touches every bank once; V is read along rows
-// (16 lanes = the 16 chunks of one row) and needs no swizzle.  Rows past N are clamped copies (finite; masked by the softmax).
-template <int NF>
-__global__ __launch_bounds__(256) void k_attention_ring(const float* __restrict__ qkv, float* __restrict__ out, int B, int N, int heads,
-                                                        int QG) {
-    constexpr int T0 = (NF + 1) / 2, T1 = NF - T0;        // key fragments of tiles 0 / 1
-    __shared__ __attribute__((aligned(16))) float smem[2 * T0 * 16 * 64];     // two slots of T0 key fragments x 16 rows x 256 B (<= 64 KiB)
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // workgroups b and b + 8 share an XCD: each XCD takes a contiguous run of (head, query group) pairs, so the QG
-    // workgroups of a head read its K / V through one L2
-    const int total = gridDim.x;
-    int bid = blockIdx.x;
-    {
-        const int q = total / 8, r = total % 8, xcd = bid % 8, loc = bid / 8;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-    }
-    const int bh = bid / QG, qg = bid - bh * QG;
-    const int b = bh / heads, hd = bh - b * heads;
-    const int base_n = NF / QG, rem_n = NF - base_n * QG;
-    const int nq = base_n + (qg < rem_n ? 1 : 0);                 // query fragments of this workgroup (<= 4)
-    const int qf = qg * base_n + min(qg, rem_n) + wave;           // this wave's query fragment
-    const bool active = wave < nq;
-    const int Cm = heads * 64;
-    const size_t rs = (size_t)3 * Cm;
-    const float* base = qkv + (size_t)b * N * rs + (size_t)hd * 64;
-    const float* qb = base;
-    const float* kb = base + Cm;
-    const float* vb = base + 2 * Cm;
-    const int g = lane >> 4, li = lane & 15;
-
-    // one tile -> one slot: pieces of 4 rows (1 KiB), piece p = wave + 4 i: every wave issues exactly `nf` LDS-DMAs per tile
-    // (fully unrolled: the waits below count them); lane l of a piece: row l>>4, chunk l&15
-    auto stage = [&](const float* src, int slot, int f0, auto nfc, bool swz) {
-        constexpr int NFT = decltype(nfc)::value;
-        float* dst = smem + (size_t)slot * (T0 * 16 * 64);
-#pragma unroll
-        for (int i = 0; i < NFT; ++i) {
-            const int p = wave + 4 * i;
-            const int rt = 4 * p + g;                              // row inside the tile
-            const int row = min(16 * f0 + rt, N - 1);
-            const int ch = swz ? (li ^ (rt & 15)) : li;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)row * rs + 4 * ch),
-                                             (__attribute__((address_space(3))) void*)(dst + p * 256), 16, 0, 0);
-        }
-    };
-    using TC0 = std::integral_constant<int, T0>;
-    using TC1 = std::integral_constant<int, T1>;
-    const int qrow = min(qf * 16 + li, N - 1);
-    float4 qv[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) qv[c] = nd_ld16<false>(qb + (size_t)qrow * rs + 16 * c + 4 * g);
-    stage(kb, 0, 0, TC0{}, true);
-    stage(kb, 1, T0, TC1{}, true);
-    f32x4 s[NF];
-#pragma unroll
-    for (int f = 0; f < NF; ++f) s[f] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // the 4 operand reads of fragment f+1 are issued before the 16 MFMAs of fragment f (pinned: left alone, hipcc reads and
-    // waits fragment by fragment and the wave sees the LDS latency 13 times)
-    auto scores = [&](int slot, auto f0c, auto nfc) {
-        constexpr int F0 = decltype(f0c)::value, NFT = decltype(nfc)::value;
-        const float* sk = smem + (size_t)slot * (T0 * 16 * 64) + li * 64;
-        f32x4 kv[2][4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) kv[0][c] = *reinterpret_cast<const f32x4*>(sk + 4 * ((4 * c + g) ^ li));
-#pragma unroll
-        for (int f = 0; f < NFT; ++f) {
-            if (f + 1 < NFT) {
-#pragma unroll
-                for (int c = 0; c < 4; ++c) kv[(f + 1) & 1][c] = *reinterpret_cast<const f32x4*>(sk + 16 * (f + 1) * 64 + 4 * ((4 * c + g) ^ li));
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                s[F0 + f] = __builtin_amdgcn_mfma_f32_16x16x4f32(kv[f & 1][c][0], qv[c].x, s[F0 + f], 0, 0, 0);
-                s[F0 + f] = __builtin_amdgcn_mfma_f32_16x16x4f32(kv[f & 1][c][1], qv[c].y, s[F0 + f], 0, 0, 0);
-                s[F0 + f] = __builtin_amdgcn_mfma_f32_16x16x4f32(kv[f & 1][c][2], qv[c].z, s[F0 + f], 0, 0, 0);
-                s[F0 + f] = __builtin_amdgcn_mfma_f32_16x16x4f32(kv[f & 1][c][3], qv[c].w, s[F0 + f], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-    // LDS-DMA is ordered for a ds_read only by the issuing wave's vmcnt wait followed by a barrier; a slot is refilled only
-    // after a barrier that every wave reaches with its reads of that slot retired (lgkmcnt(0))
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(T1) : "memory");      // each wave issued 4 q loads, T0 pieces of K0, then T1 of K1: K0 landed
-    __builtin_amdgcn_s_barrier();
-    if (active) scores(0, std::integral_constant<int, 0>{}, std::integral_constant<int, T0>{});
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                                  // slot 0 released; K1 landed
-    stage(vb, 0, 0, TC0{}, false);
-    if (T1 > 0) {
-        if (active) scores(1, std::integral_constant<int, T0>{}, std::integral_constant<int, T1>{});
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                              // slot 1 released
-        stage(vb, 1, T0, TC1{}, false);
-    }
-    // softmax over the keys (per query column q = lane & 15): in-lane over (f, r), across the 4 lane groups by xor 16 / 32
-    const float scale = 0.125f;  // 64^-0.5
-    float mx = -INFINITY;
-#pragma unroll
-    for (int f = 0; f < NF; ++f)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int key = 16 * f + 4 * g + r;
-            const float v = key < N ? s[f][r] * scale : -INFINITY;
-            s[f][r] = v;
-            mx = fmaxf(mx, v);
-        }
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    float sum = 0.f;
-#pragma unroll
-    for (int f = 0; f < NF; ++f)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float p = expf(s[f][r] - mx);
-            s[f][r] = p;
-            sum += p;
-        }
-    sum += __shfl_xor(sum, 16, 64);
-    sum += __shfl_xor(sum, 32, 64);
-    const float inv = 1.0f / sum;
-    f32x4 o[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = f32x4{0.f, 0.f, 0.f, 0.f};
-    auto pv = [&](int slot, auto f0c, auto nfc) {
-        constexpr int F0 = decltype(f0c)::value, NFT = decltype(nfc)::value;
-        const float* sv = smem + (size_t)slot * (T0 * 16 * 64) + 4 * g * 64 + 4 * li;
-        f32x4 vv[2][4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) vv[0][r] = *reinterpret_cast<const f32x4*>(sv + r * 64);
-#pragma unroll
-        for (int f = 0; f < NFT; ++f) {
-            if (f + 1 < NFT) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) vv[(f + 1) & 1][r] = *reinterpret_cast<const f32x4*>(sv + (16 * (f + 1) + r) * 64);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float p = s[F0 + f][r] * inv;              // normalised first, as torch (softmax then @ v)
-                o[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv[f & 1][r][0], p, o[0], 0, 0, 0);
-                o[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv[f & 1][r][1], p, o[1], 0, 0, 0);
-                o[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv[f & 1][r][2], p, o[2], 0, 0, 0);
-                o[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv[f & 1][r][3], p, o[3], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(T1) : "memory");      // all but this wave's T1 pieces of V1: V0 landed
-    __builtin_amdgcn_s_barrier();
-    if (active) pv(0, std::integral_constant<int, 0>{}, std::integral_constant<int, T0>{});
-    if (T1 > 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (active) pv(1, std::integral_constant<int, T0>{}, std::integral_constant<int, T1>{});
-    }
-    // o[e][r'] = O[q = l&15][d = 4*(4g + r') + e]  ->  float4 over e at d0 = 16g + 4r'
-    const int qo = qf * 16 + li;
-    if (active && qo < N) {
-        float* op = out + ((size_t)b * N + qo) * Cm + (size_t)hd * 64 + 16 * g;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) *reinterpret_cast<float4*>(op + 4 * r) = make_float4(o[0][r], o[1][r], o[2][r], o[3][r]);
-    }
-}
-
-template <int NF>
-static hipError_t launch_attention_ring(const float* qkv, float* out, int B, int N, int heads, hipStream_t st) {
-    const int QG = (NF + 3) / 4;
-    hipLaunchKernelGGL((k_attention_ring<NF>), dim3(B * heads * QG), dim3(256), 0, st, qkv, out, B, N, heads, QG);
-    return hipGetLastError();
-}
+// RING form (the default fp32 kernel): nd_attention.hip, a translation unit of its own (accumulators kept in VGPRs).
+hipError_t nd_launch_attention_ring(const float* qkv, float* out, int B, int N, int heads, hipStream_t st);
 
 // fp16-operand form (the fp16 mode; not a mode of the reference): q, k, v are rounded to fp16 as they are staged, both
 // contractions run on v_mfma_f32_16x16x32_f16 with fp32 accumulation, the softmax is fp32 and the normalised probabilities
@@ -1029,7 +848,7 @@ extern "C" int nd_attention(const float* qkv, float* out, int B, int N, int head
     static const int form = getenv("ND_ATT_FORM") ? atoi(getenv("ND_ATT_FORM")) : 2;   // 2 = 4-wave ring (default), 1 = whole K/V in LDS, 0 = K/V from L2 per wave
     const dim3 grid((nf + 3) / 4, B * heads), block(256);
 #define AT_CASE(NFV) case NFV: if (dtype == ND_DTYPE_F16) HIP_CHECK((launch_attention_h<NFV>(qkv, out, B, N, heads, st)));  \
-                               else if (form == 2) HIP_CHECK((launch_attention_ring<NFV>(qkv, out, B, N, heads, st))); \
+                               else if (form == 2) HIP_CHECK(nd_launch_attention_ring(qkv, out, B, N, heads, st)); \
                                else if (form == 1) HIP_CHECK((launch_attention_lds<NFV>(qkv, out, B, N, heads, st))); \
                                else hipLaunchKernelGGL((k_attention_d64<NFV, 1, 2>), grid, block, 0, st, qkv, out, B, N, heads); break;
     switch (nf) {

@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from nested_diffusion_amd import ops
 dt = sys.argv[1] if len(sys.argv) > 1 else "f32"
-B, N, heads = 32, 196, 12
+B, N, heads = (int(sys.argv[2]) if len(sys.argv) > 2 else 32), 196, 12
 qkv = torch.randn(B * N, 3 * heads * 64, device="cuda")
 for _ in range(3): ops.attention(qkv, B, N, heads, dt)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
