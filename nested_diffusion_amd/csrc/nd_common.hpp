@@ -170,6 +170,7 @@ struct SkinnyDesc {
     const float* pw;     // [C, N]            (MODE 1)
     float* part;         // MODE 1: [M, C, ceil(N/16)];  MODE 2: [S, Mpad, Npad]
     int K, N, C, act, out_packed;
+    int keep;            // 1: this member's W is read with default-policy loads in an NT kernel (kept in the Infinity Cache across steps)
 };
 
 // WORK DECOMPOSITION.  A workgroup never mixes members (it would have to stream two activation matrices and finishes
@@ -305,11 +306,12 @@ __global__ __launch_bounds__(WAVES * 64) void k_skinny(SkinnyDesc d0, const Skin
 #undef ND_MIX
         if (i < ngw) MMA(wA, xA);
     };
+    const bool nt_here = NT && !d.keep;
     if (nact == NF) {
-        if (NT) run(std::true_type{}, std::true_type{});
+        if (nt_here) run(std::true_type{}, std::true_type{});
         else run(std::false_type{}, std::true_type{});
     } else {
-        if (NT) run(std::true_type{}, std::false_type{});
+        if (nt_here) run(std::true_type{}, std::false_type{});
         else run(std::false_type{}, std::false_type{});
     }
     // leftover chunks (chunk count not a multiple of U): chunk c goes to wave c % WAVES
