@@ -38,3 +38,6 @@ for mode, name in ((0, "lin2 (MODE 0)"), (1, "lin3+lin4 (MODE 1)")):
           f"activated-loop mean {(act - loop_end).mean():.2f}  end-activated mean {(end - act).mean():.2f}  end max {end.max():.2f} us")
     heavy = [0, 51, 102, 153, 204]
     print("   6-fragment workgroups end at", [round(float(end[i]), 1) for i in heavy])
+    for g in range(K):       # per member (51 workgroups each): members 0..2 of lin2 read Infinity-Cache resident weights
+        sl = slice(51 * g, 51 * g + 51)
+        print(f"   member {g}: loop-end mean {loop_end[sl].mean():.2f} max {loop_end[sl].max():.2f}  end max {end[sl].max():.2f} us")
