@@ -265,6 +265,8 @@ def main():
             except Exception:
                 traffic = None
         roof["traffic"] = traffic
+        roof["note"] = ("bytes delivered to the CUs per second: ~208 MB of the 2*K*F*F*4 weight bytes a step reads are kept resident in the "
+                        "256 MiB Infinity Cache across steps (default-policy loads; the rest streams from HBM with nontemporal loads)")
         roof["traffic_source"] = ("profiles/traffic.json: rocprofv3 PMC (FETCH_SIZE x2 + WRITE_SIZE, separate passes) of this kernel at this "
                                   "shape, REPLAYED from the committed profile, not measured by this run") if traffic else None
     else:
