@@ -24,155 +24,16 @@ static hipError_t nd_allow_dynamic_lds(const void* fn, size_t bytes, unsigned lo
     return e;
 }
 
+// fp32 GEMM kernel: nd_gemm_f32.hip (its own translation unit, accumulators in VGPRs)
+hipError_t nd_launch_gemm_nt_128x64(const float* x, const float* w, const float* bias, const float* res, float* out, int M, int K, int N,
+                                    int act, int n_full, int split, float* part, unsigned grid, hipStream_t st);
 // ---------------------------------------------------------------------------------------------
 // Large-M GEMM, both operands K-contiguous:  out[m,n] = act(sum_k x[m,k] w[n,k] + bias[n]) + res[m,n]
-// Workgroup tile BM x BN (256 threads = 2x2 waves), BK = 16 per stage, two LDS stages filled through
-// registers (loads for stage s+1 issued before the MFMAs of stage s, written after them).
-// LDS rows are 16 floats + 8 pad so a lane's float4 (k = 4*(l>>4)..+3) is one conflict-free ds_read_b128; MFMA jj
-// takes element jj of every lane (k order permuted identically on both operands).
-// Measured on MI355X: 126-129 TFLOP/s at 4096^3 / 8192x4096x4096 (82 % of the 157 TF f32-MFMA peak), 80-100 TF on
-// the ViT shapes (M = 6272: the tile grid does not fill the last round of CUs).  A 32x32x2-MFMA / BK=32 tiling of the
-// same structure measured slower on every ViT shape and was dropped.
+// The fp32 kernel (k_gemm_nt<128,64>: 3-stage pipeline, one barrier per K-step) lives in nd_gemm_f32.hip; this file holds the
+// launch plan, the k-split fixup and the fp16-operand form.
 // ---------------------------------------------------------------------------------------------
 #define GB_K 16
 #define GB_LD 24   // 16 + 8 pad: ds_read_b128 of (row = l&15, k-quad = l>>4) is bank-conflict-free
-
-template <int BM, int BN>
-__global__ __launch_bounds__(256) void k_gemm_nt(const float* __restrict__ x, const float* __restrict__ w,
-                                                 const float* __restrict__ bias, const float* __restrict__ res,
-                                                 float* __restrict__ out, int M, int K, int N, int act, int n_full,
-                                                 int split, float* __restrict__ part) {
-    constexpr int WM = BM / 2, WN = BN / 2;      // per-wave tile
-    constexpr int FM = WM / 16, FN = WN / 16;    // 16x16 fragments per wave
-    constexpr int LA = BM * GB_K / 4 / 256;      // float4 loads per thread for the x tile
-    constexpr int LB = BN * GB_K / 4 / 256;
-    static_assert(LA >= 1 && LB >= 1, "tile too small");
-    __shared__ __attribute__((aligned(16))) float sA[2][BM][GB_LD];
-    __shared__ __attribute__((aligned(16))) float sB[2][BN][GB_LD];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
-    // XCD-aware tile order: consecutive tiles along N (sharing the x panel) land on one XCD
-    const int tiles_n = (N + BN - 1) / BN;
-    // Workgroups [0, n_full) take one whole tile each; the remaining tiles are cut into `split` k-slabs, one workgroup per
-    // slab, whose raw sums go to `part` and are finished by k_gemm_fixup (the tail of the launch is then `split` times finer).
-    int bid = blockIdx.x, slab = -1;
-    if (bid < n_full) {
-        const int q = n_full / 8, r = n_full % 8, xcd = bid % 8, loc = bid / 8;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-    } else {
-        const int j = bid - n_full;
-        bid = n_full + j / split;
-        slab = j % split;
-    }
-    const int tm = bid / tiles_n, tn = bid % tiles_n;
-    const int m0 = tm * BM, n0 = tn * BN;
-
-    f32x4 acc[FM][FN];
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // staging map: thread -> (row, kq) with 4 threads per 16-float row.  Written as macros, not lambdas: arrays
-    // captured by reference end up in scratch memory.
-    float4 ra[LA], rb[LB];
-#define GB_GLOAD(k0)                                                                                      \
-    {                                                                                                     \
-        _Pragma("unroll") for (int i = 0; i < LA; ++i) {                                                  \
-            const int e = tid + i * 256, row = e >> 2, kq = (e & 3) * 4;                                  \
-            ra[i] = *reinterpret_cast<const float4*>(x + (size_t)min(m0 + row, M - 1) * K + (k0) + kq);  \
-        }                                                                                                 \
-        _Pragma("unroll") for (int i = 0; i < LB; ++i) {                                                  \
-            const int e = tid + i * 256, row = e >> 2, kq = (e & 3) * 4;                                  \
-            rb[i] = *reinterpret_cast<const float4*>(w + (size_t)min(n0 + row, N - 1) * K + (k0) + kq);  \
-        }                                                                                                 \
-    }
-#define GB_SWRITE(buf)                                                                                    \
-    {                                                                                                     \
-        _Pragma("unroll") for (int i = 0; i < LA; ++i) {                                                  \
-            const int e = tid + i * 256, row = e >> 2, kq = (e & 3) * 4;                                  \
-            *reinterpret_cast<float4*>(&sA[buf][row][kq]) = ra[i];                                        \
-        }                                                                                                 \
-        _Pragma("unroll") for (int i = 0; i < LB; ++i) {                                                  \
-            const int e = tid + i * 256, row = e >> 2, kq = (e & 3) * 4;                                  \
-            *reinterpret_cast<float4*>(&sB[buf][row][kq]) = rb[i];                                        \
-        }                                                                                                 \
-    }
-
-    const int nkt = K / GB_K;
-    const int ks0 = slab < 0 ? 0 : (int)((long)slab * nkt / split);
-    const int nk = slab < 0 ? nkt : (int)((long)(slab + 1) * nkt / split);
-    GB_GLOAD(ks0 * GB_K)
-    GB_SWRITE(ks0 & 1)
-    __syncthreads();
-    const int lr = lane & 15, lk = 4 * (lane >> 4);
-    for (int ks = ks0; ks < nk; ++ks) {
-        const int buf = ks & 1;
-        // unconditional (clamped) prefetch + write-back: conditionally assigned staging arrays are kept in scratch
-        // memory by hipcc; the last step re-stages a valid tile that nobody reads
-        GB_GLOAD(min(ks + 1, nk - 1) * GB_K)
-        float4 fa[FM], fb[FN];
-#pragma unroll
-        for (int i = 0; i < FM; ++i) fa[i] = *reinterpret_cast<const float4*>(&sA[buf][wr * WM + 16 * i + lr][lk]);
-#pragma unroll
-        for (int j = 0; j < FN; ++j) fb[j] = *reinterpret_cast<const float4*>(&sB[buf][wc * WN + 16 * j + lr][lk]);
-        // k-quad outermost: 16 independent accumulators between two MFMAs on the same one (the f32 MFMA's
-        // dependent latency, 40 cycles, exceeds its 32-cycle issue interval)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-#pragma unroll
-            for (int i = 0; i < FM; ++i) {
-                const float av = q == 0 ? fa[i].x : q == 1 ? fa[i].y : q == 2 ? fa[i].z : fa[i].w;
-#pragma unroll
-                for (int j = 0; j < FN; ++j) {
-                    const float bv = q == 0 ? fb[j].x : q == 1 ? fb[j].y : q == 2 ? fb[j].z : fb[j].w;
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv, av, acc[i][j], 0, 0, 0);   // D[i=n][j=m]
-                }
-            }
-        }
-        GB_SWRITE(buf ^ 1)
-        __syncthreads();
-    }
-#undef GB_GLOAD
-#undef GB_SWRITE
-    // D[n = 4*(l>>4)+r][m = l&15]: a lane owns 4 consecutive n of one row m
-    if (slab >= 0) {
-        float* pt = part + ((size_t)(bid - n_full) * split + slab) * (BM * BN);
-#pragma unroll
-        for (int i = 0; i < FM; ++i)
-#pragma unroll
-            for (int j = 0; j < FN; ++j)
-                *reinterpret_cast<float4*>(pt + (wr * WM + 16 * i + (lane & 15)) * BN + wc * WN + 16 * j + 4 * (lane >> 4)) =
-                    make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-        return;
-    }
-#pragma unroll
-    for (int i = 0; i < FM; ++i) {
-        const int m = m0 + wr * WM + 16 * i + (lane & 15);
-#pragma unroll
-        for (int j = 0; j < FN; ++j) {
-            const int n = n0 + wc * WN + 16 * j + 4 * (lane >> 4);
-            if (m < M && n < N) {
-                float v[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int nn = min(n + r, N - 1);
-                    float t = acc[i][j][r] + (bias ? bias[nn] : 0.f);
-                    t = nd_act(t, act);
-                    if (res && n + r < N) t += res[(size_t)m * N + n + r];
-                    v[r] = t;
-                }
-                float* p = out + (size_t)m * N + n;
-                if (n + 3 < N && (N & 3) == 0) *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
-                else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) if (n + r < N) p[r] = v[r];
-                }
-            }
-        }
-    }
-}
-
 
 // ---------------------------------------------------------------------------------------------
 // fp16-operand form of the same GEMM (the fp16 mode, BASELINE config 5; not a mode of the reference):
@@ -387,8 +248,7 @@ extern "C" int nd_gemm_bias_act(const float* x, const void* w, const float* bias
         hipLaunchKernelGGL((k_gemm_h<GT_BM, GT_BN>), grid, dim3(256), 0, st, x, (const _Float16*)w, bias, res, out, M, K, N, act, p.n_full,
                            p.split, part);
     else
-        hipLaunchKernelGGL((k_gemm_nt<GT_BM, GT_BN>), grid, dim3(256), 0, st, x, (const float*)w, bias, res, out, M, K, N, act, p.n_full,
-                           p.split, part);
+        HIP_CHECK(nd_launch_gemm_nt_128x64(x, (const float*)w, bias, res, out, M, K, N, act, p.n_full, p.split, part, grid.x, st));
     HIP_CHECK(hipGetLastError());
     if (p.rem > 0) {
         hipLaunchKernelGGL((k_gemm_fixup<GT_BM, GT_BN>), dim3(GT_BM * GT_BN / 4 / 256, p.rem), dim3(256), 0, st, part, bias, res, out, M, N,
