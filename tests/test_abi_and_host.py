@@ -181,6 +181,54 @@ def test_image_folder_pipeline(tmp_path):
         get_test_loader(args, cfg)
 
 
+def test_image_folder_transforms_against_hand_arithmetic(tmp_path):
+    """Independent expectations for the reference's test-time transforms (dataset_helper/chest_x_ray_dataset.py:31-51; torchvision
+    on PIL images), written out in numpy instead of calling PIL again:
+      Grayscale(3): ITU-R 601-2 luma in PIL's 16-bit fixed point, L = (19595 R + 38470 G + 7471 B + 32768) >> 16, replicated;
+      Resize((224,224)) of a 448x448 image: PIL BILINEAR is a triangle filter whose support scales with the reduction, i.e. taps
+      (1, 3, 3, 1)/8 per axis at a factor of 2 (each pass rounds to 8 bits with fixed-point taps: tolerance 1.5 grey levels, mean error < 0.35);  ToTensor: /255."""
+    import numpy as np
+    from PIL import Image
+    from nested_diffusion_amd.data import ImageFolderDataset
+    rng = np.random.default_rng(7)
+    root = tmp_path / "testing"
+    (root / "NORMAL").mkdir(parents=True)
+    same = rng.integers(0, 256, size=(224, 224, 3), dtype=np.uint8)          # already 224 x 224: the resize is the identity
+    big = rng.integers(0, 256, size=(448, 448, 3), dtype=np.uint8)
+    Image.fromarray(same, "RGB").save(root / "NORMAL" / "a_same.png")
+    Image.fromarray(big, "RGB").save(root / "NORMAL" / "b_big.png")
+    ds = ImageFolderDataset(str(root), "ChestXRay", "grayscaled")
+    x_same, x_big = ds[0][0].numpy(), ds[1][0].numpy()
+    def luma(a):
+        a = a.astype(np.int64)
+        return ((19595 * a[..., 0] + 38470 * a[..., 1] + 7471 * a[..., 2] + 32768) >> 16).astype(np.float64)
+    exp_same = luma(same) / 255.0
+    for c in range(3):
+        assert np.array_equal(x_same[c].astype(np.float64), exp_same.astype(np.float32).astype(np.float64)), c
+    g = luma(big)
+    taps = np.array([1, 3, 3, 1], dtype=np.float64) / 8.0
+
+    def down2(a, axis):                                                   # output i takes inputs 2i-1 .. 2i+2 (edges: renormalised)
+        a = np.moveaxis(a, axis, 0)
+        n = a.shape[0] // 2
+        out = np.zeros((n,) + a.shape[1:])
+        for i in range(n):
+            idx = np.arange(2 * i - 1, 2 * i + 3)
+            ok = (idx >= 0) & (idx < a.shape[0])
+            wgt = taps[ok] / taps[ok].sum()
+            out[i] = np.tensordot(wgt, a[idx[ok]], axes=(0, 0))
+        return np.moveaxis(out, 0, axis)
+    exp_big = down2(np.rint(down2(g, 1)), 0) / 255.0                      # PIL: horizontal pass (rounded to 8 bits), then vertical
+    assert np.abs(x_big[0].astype(np.float64) - exp_big).max() <= 1.5 / 255
+    assert np.abs(x_big[0].astype(np.float64) - exp_big).mean() < 0.35 / 255
+    assert np.array_equal(x_big[0], x_big[1]) and np.array_equal(x_big[1], x_big[2])
+    # standardized: no grayscale; (x/255 - mean) / std with the reference's pre-calculated constants (:73-74)
+    xs = ImageFolderDataset(str(root), "ChestXRay", "standardized")[0][0].numpy()
+    mean, std = np.array([0.5094, 0.5234, 0.5289]), np.array([0.2189, 0.2225, 0.2244])
+    exp = (same.transpose(2, 0, 1).astype(np.float32) / 255 - mean[:, None, None].astype(np.float32)) / std[:, None, None].astype(np.float32)
+    assert np.abs(xs - exp).max() < 1e-6
+
+
 def test_launch_plans_on_the_host():
     """The launch-plan helpers are host code: the headline shapes must give at most one 4-wave workgroup per CU, every
     fragment covered, every k-chunk covered, and the ViT GEMM must ask for a tail workspace only where a partial last round
