@@ -91,6 +91,37 @@ def test_sampler_fp16_vs_oracle_fp16_mode(D, H, Fd, C, T, B, mc):
     assert (y0 - ref32).abs().max().item() < 2e-2
 
 
+def test_sampler_fp16_config_dims_isic_shape():
+    """BASELINE configs[4] in its real dimensions (ISICSkinCancer YAML dims = chest_x_ray dims: D = 150528, F = H = 4096,
+    temperature 0.3162), fp16-operand mode, one member, T = 20 of the 1000-step schedule's length class, B = 8, mc = 2 -- against the
+    oracle's fp16-operand mode and against the fp32 reference arithmetic.  (The fp16 mode is not a reference mode: unpinned by
+    nature; this checks the full-size split-K encoder stream, the frag32h step kernels and the Infinity-Cache residency split at
+    config dims.)  Tolerances as in the small-shape test: 2e-3 relative on xe, 5e-3 absolute on y_0, 2e-2 against fp32."""
+    from nested_diffusion_amd.engine import EnsembleEngine
+    D, H, Fd, C, T, B, mc = 150528, 4096, 4096, 2, 20, 8, 2
+    p = ref_cpu.init_cond_model_params(D, H, Fd, C, T, True, seed=77)
+    g = torch.Generator().manual_seed(15)
+    x = torch.rand(B, D, generator=g)
+    yhat = torch.softmax(torch.randn(B, C, generator=g), -1)
+    alphas, omabs = ref_cpu.schedule_tables("linear", T, 1e-4, 0.02)
+    eng = EnsembleEngine(C, D, H, Fd, T, n_members=1, max_batch=B, max_rows=B * mc, dtype="f16")
+    eng.load_member(0, p)
+    eng.set_schedule(alphas, omabs)
+    eng.encode(x)
+    with ref_cpu.fp16_operands():
+        xe_ref = ref_cpu.encoder_x(p, x)
+    _close(eng.member_buffer(0, 0, B).cpu(), xe_ref, 2e-3)
+    noise = torch.randn(T, B * mc, C, generator=g)
+    y0 = eng.sample(yhat[None], yhat[None], noise[None], mc=mc, T=T)[0].cpu()
+    with ref_cpu.fp16_operands():
+        ref = ref_cpu.p_sample_loop(p, x.repeat(mc, 1), yhat.repeat(mc, 1), yhat.repeat(mc, 1), T, alphas, omabs, noise, True)
+    ref32 = ref_cpu.p_sample_loop(p, x.repeat(mc, 1), yhat.repeat(mc, 1), yhat.repeat(mc, 1), T, alphas, omabs, noise, True)
+    d16, d32 = (y0 - ref).abs().max().item(), (y0 - ref32).abs().max().item()
+    pr = (ref_cpu.convert_to_prob(y0, 0.3162) - ref_cpu.convert_to_prob(ref32, 0.3162)).abs().max().item()
+    print(f"fp16 mode at config dims: max |y0 - oracle fp16| = {d16:.2e}, max |y0 - fp32 reference arithmetic| = {d32:.2e}, class-prob delta vs fp32 = {pr:.2e}")
+    assert d16 < 5e-3 and d32 < 2e-2
+
+
 def test_classifier_fp16_vs_oracle_fp16_mode():
     from nested_diffusion_amd.mapping import Classifier
     p = ref_cpu.init_classifier_params(64 * 6, widths=(96, 64, 32), num_classes=2, seed=3)

@@ -13,7 +13,7 @@ from oracle import ref_cpu
 
 pytestmark = pytest.mark.gpu
 
-K, T, B, C = 5, 100, 32, 2
+K, T, B, C, MC = 5, 100, 32, 2, 20
 D, H, F = 3 * 224 * 224, 4096, 4096
 
 
@@ -36,7 +36,7 @@ def headline():
     states = [synthetic.cond_model_state(D, H, F, C, T, seed=1000 + k, device=dev) for k in range(K)]
     cond = GuidingConditioner(VisionTransformer(vit_sd, 12, dev), [Classifier(m, dev) for m in mlp_sd])
     runner = Diffusion(ns(seed=1234, mc_trials=1), cfg, device=dev, conditioner=cond, noise_estimator_states=list(states))
-    runner.load_noise_estimators(max_batch=B, mc_trials=1)
+    runner.load_noise_estimators(max_batch=B, mc_trials=MC)           # workspace sized for the mc_trials = 20 test below
     cpu = lambda sd: {k: v.cpu() for k, v in sd.items()}
     host = {"vit": cpu(vit_sd), "mlps": [cpu(m) for m in mlp_sd], "members": [cpu(s) for s in states]}
     del vit_sd, mlp_sd, states
@@ -94,4 +94,45 @@ def test_headline_config_end_to_end_class_probability_delta(headline):
     margin = (ref.topk(2, dim=2).values[..., 0] - ref.topk(2, dim=2).values[..., 1]).amin(dim=0)
     safe = margin > 10 * d_y0
     assert safe.sum() >= B - 2
+    assert torch.equal(out["vote"].cpu()[safe], vote[safe])
+
+
+def test_reference_mc_trials_20_end_to_end(headline):
+    """The reference's own trial count (mc_trials = 20, classification_train_separately.py:770-771) at the headline dims: K = 5,
+    T = 100, B = 32 -> 640 rows per member through the LDS-tiled k_cond_gemm at every step, 100 samples per image aggregated.
+    Rows are trial-major (row = trial * B + image); the oracle runs each member's 20 trials as one 640-row batch (rows are
+    independent in eval mode).  Same criterion: class probabilities within 1e-3, votes equal away from ties."""
+    runner, host = headline
+    g = torch.Generator().manual_seed(177)
+    x = torch.rand(B, 3, 224, 224, generator=g)
+    noise = torch.randn(K, T, MC * B, C, generator=g)                    # engine layout [K, T, trial*B + image, C]
+    out = runner.predict_batch(x.cuda(), noise=noise.cuda(), mc_trials=MC)
+    torch.cuda.synchronize()
+    assert runner.engine.step_plan(MC * B)["kernel"] == "k_cond_gemm"
+    t0 = time.time()
+    logits = ref_cpu.compute_guiding_prediction(host["vit"], host["mlps"], x, 12, 12, full_vit=False, share_prefix=True)
+    yhat = [torch.softmax(l, dim=1) for l in logits]
+    alphas, omabs = ref_cpu.schedule_tables("linear", T, 1e-4, 0.02)
+    samples = []
+    for k in range(K):
+        y0 = ref_cpu.p_sample_loop(host["members"][k], x.flatten(1).repeat(MC, 1), yhat[k].repeat(MC, 1), yhat[k].repeat(MC, 1), T,
+                                   alphas, omabs, noise[k], True, hoist=True)                 # [MC*B, C]
+        samples += [y0[j * B:(j + 1) * B] for j in range(MC)]                                 # member-major, then trial (:767-784)
+    vote = ref_cpu.majority_voting_for_mc_samples(samples)
+    ref = torch.stack(samples)
+    prob = ref_cpu.compute_ensemble_confidence([s_.clone() for s_ in samples], runner.temperature)
+    cpu_s = time.time() - t0
+    got = out["samples"].cpu()
+    assert got.shape == ref.shape == (K * MC, B, C)
+    d_y0 = (got - ref).abs().max().item()
+    d_prob = (out["prob"].cpu() - prob).abs().max().item()
+    print(f"mc_trials=20 K={K} T={T} B={B}: max |class-prob delta| = {d_prob:.3e}, max |y0 delta| = {d_y0:.3e} "
+          f"(|y0| max {ref.abs().max().item():.2f}); oracle took {cpu_s:.1f} s")
+    assert d_prob <= 1e-3
+    assert d_y0 < 1e-4 * max(1.0, ref.abs().max().item())
+    # majority vote over 100 samples per image: equal unless the top two counts tie in the oracle
+    am = ref.argmax(dim=2)                                                # [K*MC, B]
+    counts = torch.stack([(am == c).sum(dim=0) for c in range(C)], dim=1)
+    top2 = counts.topk(2, dim=1).values
+    safe = (top2[:, 0] - top2[:, 1]) > 2
     assert torch.equal(out["vote"].cpu()[safe], vote[safe])
