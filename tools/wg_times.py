@@ -30,7 +30,7 @@ for _ in range(3):
 torch.cuda.synchronize()
 h = buf.cpu().reshape(3, 2, 4096, 3)
 for mode, name in ((0, "lin2 (MODE 0)"), (1, "lin3+lin4 (MODE 1)")):
-    t = h[mode, 0, :255].double(); u = h[mode, 1, :255].double()
+    t = h[mode, 0, :256].double(); u = h[mode, 1, :256].double()
     t0 = t[:, 0].min()
     start, loop_end, end = (t[:, 0] - t0) / 100, (t[:, 1] - t0) / 100, (t[:, 2] - t0) / 100
     redw, act = (u[:, 0] - t0) / 100, (u[:, 1] - t0) / 100
@@ -41,3 +41,5 @@ for mode, name in ((0, "lin2 (MODE 0)"), (1, "lin3+lin4 (MODE 1)")):
     for g in range(K):       # per member (51 workgroups each): members 0..2 of lin2 read Infinity-Cache resident weights
         sl = slice(51 * g, 51 * g + 51)
         print(f"   member {g}: loop-end mean {loop_end[sl].mean():.2f} max {loop_end[sl].max():.2f}  end max {end[sl].max():.2f} us")
+    order = torch.argsort(end, descending=True)[:8]
+    print("   latest workgroups:", [(int(i), round(float(loop_end[i]), 1), round(float(end[i]), 1)) for i in order])
