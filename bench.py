@@ -151,8 +151,8 @@ def cpu_baseline(members_cpu, vit_cpu, mlps_cpu, images_cpu, out_gpu, noise, T_f
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="images per GPU")
     ap.add_argument("--members", type=int, default=5)
     ap.add_argument("--timesteps", type=int, default=100)
