@@ -203,7 +203,7 @@ def main():
             torch.cuda.synchronize(device)
         dt = time.perf_counter() - t0
         if world > 1:
-            tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+            tmax = torch.tensor([dt], dtype=torch.float64, device=device if torch.distributed.get_backend() == "nccl" else "cpu")
             torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
             dt = float(tmax.item())
         return dt, out

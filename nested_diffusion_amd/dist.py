@@ -30,12 +30,17 @@ def init_from_env(backend: str = None) -> Tuple[int, int, int]:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # ND_DIST_BACKEND=gloo: rehearsal of the N > 1 path on a box with fewer GPUs than ranks (the ranks then share devices)
+            backend = os.environ.get("ND_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        if torch.cuda.is_available():
+            local = local % max(torch.cuda.device_count(), 1)
         if backend == "nccl":
             torch.cuda.set_device(local)
             td.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
         else:
             td.init_process_group(backend, rank=rank, world_size=world)
+    elif torch.cuda.is_available():
+        local = local % max(torch.cuda.device_count(), 1)
     return rank, local, world
 
 
