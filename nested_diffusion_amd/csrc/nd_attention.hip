@@ -124,25 +124,22 @@ __global__ __launch_bounds__(256) void k_attention_ring(const float* __restrict_
         f32x4 kv[2][NFT];
 #pragma unroll
         for (int f = 0; f < NFT; ++f) kv[0][f] = *reinterpret_cast<const f32x4*>(sk + 16 * f * 64 + 4 * (g ^ li));
+        __builtin_amdgcn_sched_barrier(0);             // all of chunk 0's reads in flight before the first MFMA (one latency, not NFT)
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            if (c + 1 < 4) {
-#pragma unroll
-                for (int f = 0; f < NFT; ++f) kv[(c + 1) & 1][f] = *reinterpret_cast<const f32x4*>(sk + 16 * f * 64 + 4 * ((4 * (c + 1) + g) ^ li));
-            }
             const float qq[4] = {qv[c].x, qv[c].y, qv[c].z, qv[c].w};
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj)
+            for (int jj = 0; jj < 4; ++jj) {
+                // chunk c+1's operand reads, dealt over the four k-steps of chunk c (fragment f goes with k-step f % 4)
+                if (c + 1 < 4) {
+#pragma unroll
+                    for (int f = jj; f < NFT; f += 4)
+                        kv[(c + 1) & 1][f] = *reinterpret_cast<const f32x4*>(sk + 16 * f * 64 + 4 * ((4 * (c + 1) + g) ^ li));
+                }
 #pragma unroll
                 for (int f = 0; f < NFT; ++f) s[F0 + f] = __builtin_amdgcn_mfma_f32_16x16x4f32(kv[c & 1][f][jj], qq[jj], s[F0 + f], 0, 0, 0);
-            if (c + 1 < 4) {
-#pragma unroll
-                for (int k = 0; k < NFT; ++k) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                }
+                __builtin_amdgcn_sched_barrier(0);     // pins the order: consecutive MFMAs on different accumulators, reads in their shadow
             }
-            __builtin_amdgcn_sched_barrier(0);
         }
     };
     auto pv = [&](auto tc) {
@@ -152,28 +149,19 @@ __global__ __launch_bounds__(256) void k_attention_ring(const float* __restrict_
         f32x4 vv[2][4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) vv[0][r] = *reinterpret_cast<const f32x4*>(sv + r * 64);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int f = 0; f < NFT; ++f) {
-            if (f + 1 < NFT) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) vv[(f + 1) & 1][r] = *reinterpret_cast<const f32x4*>(sv + (16 * (f + 1) + r) * 64);
-            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
+                if (f + 1 < NFT) vv[(f + 1) & 1][r] = *reinterpret_cast<const f32x4*>(sv + (16 * (f + 1) + r) * 64);
                 const float p = s[F0 + f][r] * inv;              // normalised first, as torch (softmax then @ v)
                 o[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv[f & 1][r][0], p, o[0], 0, 0, 0);
                 o[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv[f & 1][r][1], p, o[1], 0, 0, 0);
                 o[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv[f & 1][r][2], p, o[2], 0, 0, 0);
                 o[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv[f & 1][r][3], p, o[3], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            if (f + 1 < NFT) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
         }
     };
     // softmax over the keys (per query column q = lane & 15): in-lane over (f, r), across the 4 lane groups by xor 16 / 32
