@@ -324,245 +324,14 @@ extern "C" int nd_layernorm(const float* x, const float* gamma, const float* bet
 }
 
 // ---------------------------------------------------------------------------------------------
-// Attention core for d = 64.  One wave per 16 query rows of one (batch, head); K/V fragments come
-// straight from L2 as MFMA operands (each K/V row is 256 contiguous bytes).
+// Attention core for d = 64:  out = softmax(q k^T / 8) v per (image, head), q/k/v read from the fused qkv activations.
+// MFMA operand maps shared by the fp32 kernel (nd_attention.hip) and the fp16-operand kernel below:
 //   S^T = K Q^T   : A = K[key=16f+(l&15)][d=16c+4g+jj], B = Q[q=l&15][same d]  -> D[key=16f+4g+r][q=l&15]
 //   softmax over keys: in-lane over (f, r), across the 4 lane groups g by xor 16/32.
-//   O^T = V^T P^T : the k-step (f, r) takes key 16f+4g+r from lane group g -- exactly the S^T
-//                   register acc[f][r] of that lane -- and A = V[key][4*(l&15)+e] (float4, e = d-frag),
-//                   so no transpose or LDS is needed.  D_e[i=4g'+r'][q] holds d = 4*i + e.
+//   O^T = V^T P^T : the k-step (f, r) takes key 16f+4g+r from lane group g -- exactly the S^T register acc[f][r] of that
+//                   lane -- and A = V[key][4*(l&15)+e] (float4, e = d-frag), so P needs no transpose.  D_e[i=4g'+r'][q]: d = 4*i + e.
 // ---------------------------------------------------------------------------------------------
 #define AT_MAXF 16  // up to 256 keys
-// QF = 16-row query fragments per wave: every K / V fragment load feeds QF times the MFMAs (the kernel is bound by the
-// L2 -> L1 stream of K/V, 256 B per MFMA at QF = 1).
-template <int NF, int QF, int MINW>
-__global__ __launch_bounds__(256, MINW) void k_attention_d64(const float* __restrict__ qkv, float* __restrict__ out, int B, int N,
-                                                       int heads) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int qf0 = (blockIdx.x * 4 + wave) * QF;          // first 16-row query fragment of this wave
-    const int bh = blockIdx.y, b = bh / heads, hd = bh % heads;
-    if (qf0 * 16 >= N) return;
-    const int Cm = heads * 64;
-    const size_t rs = (size_t)3 * Cm;                      // token stride in qkv
-    const float* base = qkv + (size_t)b * N * rs + (size_t)hd * 64;
-    const float* qb = base;                                // q: [.., 0, hd, :]
-    const float* kb = base + Cm;
-    const float* vb = base + 2 * Cm;
-    const int g = lane >> 4, li = lane & 15;
-    float4 qv[QF][4];
-#pragma unroll
-    for (int u = 0; u < QF; ++u) {
-        const int qrow = min((qf0 + u) * 16 + li, N - 1);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) qv[u][c] = *reinterpret_cast<const float4*>(qb + (size_t)qrow * rs + 16 * c + 4 * g);
-    }
-    f32x4 s[QF][NF];
-#pragma unroll
-    for (int f = 0; f < NF; ++f) {
-#pragma unroll
-        for (int u = 0; u < QF; ++u) s[u][f] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const int krow = min(16 * f + li, N - 1);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const float4 kv = *reinterpret_cast<const float4*>(kb + (size_t)krow * rs + 16 * c + 4 * g);
-#pragma unroll
-            for (int u = 0; u < QF; ++u) {
-                s[u][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(kv.x, qv[u][c].x, s[u][f], 0, 0, 0);
-                s[u][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(kv.y, qv[u][c].y, s[u][f], 0, 0, 0);
-                s[u][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(kv.z, qv[u][c].z, s[u][f], 0, 0, 0);
-                s[u][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(kv.w, qv[u][c].w, s[u][f], 0, 0, 0);
-            }
-        }
-    }
-    // scale, mask invalid keys, softmax over keys (per query column q = lane & 15)
-    const float scale = 0.125f;  // 64^-0.5
-    float inv[QF];
-#pragma unroll
-    for (int u = 0; u < QF; ++u) {
-        float mx = -INFINITY;
-#pragma unroll
-        for (int f = 0; f < NF; ++f)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = 16 * f + 4 * g + r;
-                const float v = key < N ? s[u][f][r] * scale : -INFINITY;
-                s[u][f][r] = v;
-                mx = fmaxf(mx, v);
-            }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        float sum = 0.f;
-#pragma unroll
-        for (int f = 0; f < NF; ++f)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float p = expf(s[u][f][r] - mx);
-                s[u][f][r] = p;
-                sum += p;
-            }
-        sum += __shfl_xor(sum, 16, 64);
-        sum += __shfl_xor(sum, 32, 64);
-        inv[u] = 1.0f / sum;
-    }
-    f32x4 o[QF][4];
-#pragma unroll
-    for (int u = 0; u < QF; ++u)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[u][e] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int f = 0; f < NF; ++f)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int key = min(16 * f + 4 * g + r, N - 1);
-            const float4 vv = *reinterpret_cast<const float4*>(vb + (size_t)key * rs + 4 * li);
-#pragma unroll
-            for (int u = 0; u < QF; ++u) {
-                const float p = s[u][f][r] * inv[u];     // normalised first, as torch (softmax then @ v)
-                o[u][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv.x, p, o[u][0], 0, 0, 0);
-                o[u][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv.y, p, o[u][1], 0, 0, 0);
-                o[u][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv.z, p, o[u][2], 0, 0, 0);
-                o[u][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv.w, p, o[u][3], 0, 0, 0);
-            }
-        }
-    // o[u][e][r'] = O[q = l&15][d = 4*(4g + r') + e]  ->  float4 over e at d0 = 16g + 4r'
-#pragma unroll
-    for (int u = 0; u < QF; ++u) {
-        const int qo = (qf0 + u) * 16 + li;
-        if (qo < N) {
-            float* op = out + ((size_t)b * N + qo) * Cm + (size_t)hd * 64 + 16 * g;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) *reinterpret_cast<float4*>(op + 4 * r) = make_float4(o[u][0][r], o[u][1][r], o[u][2][r], o[u][3][r]);
-        }
-    }
-}
-
-// LDS form: one workgroup per (batch, head); its ceil(N/16) waves (one 16-row query fragment each) share the head's K
-// and V, staged once into LDS with coalesced float4 loads.  Rows are padded to 68 floats so the MFMA-operand reads
-// (ds_read_b128: K by (key = l&15, d-quad), V by (key = 4g+r, d = 4*(l&15))) are at most 2-way bank conflicted; rows
-// N .. 16*NF-1 are zero-filled, so no clamping in the inner loops.  Same arithmetic and operand maps as above.
-#define AT_LD 68
-template <int NF>
-__global__ __launch_bounds__(NF * 64) void k_attention_lds(const float* __restrict__ qkv, float* __restrict__ out, int B, int N,
-                                                            int heads) {
-    // grid.y query splits: a workgroup of blockDim.x/64 waves stages the whole K and V of its (image, head) and owns the
-    // query fragments blockIdx.y*waves .. +waves-1 (finer workgroups: less idle tail on 256 CUs, fewer waves per SIMD)
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* sK = smem;                       // [16*NF][AT_LD]
-    float* sV = smem + 16 * NF * AT_LD;
-    const int tid = threadIdx.x, lane = tid & 63, wave = blockIdx.y * (blockDim.x >> 6) + (tid >> 6);
-    const int bh = blockIdx.x, b = bh / heads, hd = bh % heads;
-    const int Cm = heads * 64;
-    const size_t rs = (size_t)3 * Cm;
-    const float* base = qkv + (size_t)b * N * rs + (size_t)hd * 64;
-    const float* qb = base;
-    const float* kb = base + Cm;
-    const float* vb = base + 2 * Cm;
-    // staging: four rows' worth of loads in flight per thread before the LDS writes (one load per trip would expose the
-    // L2 latency ceil(3328 / threads) times)
-    for (int e0 = tid; e0 < 16 * NF * 16; e0 += 4 * blockDim.x) {     // 16 float4 per 64-float row
-        float4 k4[4], v4[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int e = e0 + u * blockDim.x, row = e >> 4, c4 = (e & 15) * 4;
-            k4[u] = make_float4(0.f, 0.f, 0.f, 0.f); v4[u] = k4[u];
-            if (e < 16 * NF * 16 && row < N) {
-                k4[u] = *reinterpret_cast<const float4*>(kb + (size_t)row * rs + c4);
-                v4[u] = *reinterpret_cast<const float4*>(vb + (size_t)row * rs + c4);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int e = e0 + u * blockDim.x, row = e >> 4, c4 = (e & 15) * 4;
-            if (e < 16 * NF * 16) {
-                *reinterpret_cast<float4*>(sK + row * AT_LD + c4) = k4[u];
-                *reinterpret_cast<float4*>(sV + row * AT_LD + c4) = v4[u];
-            }
-        }
-    }
-    const int g = lane >> 4, li = lane & 15;
-    const int qrow = min(wave * 16 + li, N - 1);
-    float4 qv[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) qv[c] = *reinterpret_cast<const float4*>(qb + (size_t)qrow * rs + 16 * c + 4 * g);
-    __syncthreads();
-    f32x4 s[NF];
-#pragma unroll
-    for (int f = 0; f < NF; ++f) {
-        s[f] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const float4 kv = *reinterpret_cast<const float4*>(sK + (16 * f + li) * AT_LD + 16 * c + 4 * g);
-            s[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(kv.x, qv[c].x, s[f], 0, 0, 0);
-            s[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(kv.y, qv[c].y, s[f], 0, 0, 0);
-            s[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(kv.z, qv[c].z, s[f], 0, 0, 0);
-            s[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(kv.w, qv[c].w, s[f], 0, 0, 0);
-        }
-    }
-    const float scale = 0.125f;  // 64^-0.5
-    float mx = -INFINITY;
-#pragma unroll
-    for (int f = 0; f < NF; ++f)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int key = 16 * f + 4 * g + r;
-            const float v = key < N ? s[f][r] * scale : -INFINITY;
-            s[f][r] = v;
-            mx = fmaxf(mx, v);
-        }
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    float sum = 0.f;
-#pragma unroll
-    for (int f = 0; f < NF; ++f)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float p = expf(s[f][r] - mx);
-            s[f][r] = p;
-            sum += p;
-        }
-    sum += __shfl_xor(sum, 16, 64);
-    sum += __shfl_xor(sum, 32, 64);
-    const float inv = 1.0f / sum;
-    f32x4 o[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int f = 0; f < NF; ++f)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float4 vv = *reinterpret_cast<const float4*>(sV + (16 * f + 4 * g + r) * AT_LD + 4 * li);
-            const float p = s[f][r] * inv;
-            o[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv.x, p, o[0], 0, 0, 0);
-            o[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv.y, p, o[1], 0, 0, 0);
-            o[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv.z, p, o[2], 0, 0, 0);
-            o[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv.w, p, o[3], 0, 0, 0);
-        }
-    const int qo = wave * 16 + li;
-    if (qo < N) {
-        float* op = out + ((size_t)b * N + qo) * Cm + (size_t)hd * 64 + 16 * g;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) *reinterpret_cast<float4*>(op + 4 * r) = make_float4(o[0][r], o[1][r], o[2][r], o[3][r]);
-    }
-}
-
-template <int NF>
-static hipError_t launch_attention_lds(const float* qkv, float* out, int B, int N, int heads, hipStream_t st) {
-    const size_t lds = (size_t)2 * 16 * NF * AT_LD * sizeof(float);
-    static unsigned long long attr_done = 0;
-    {
-        hipError_t e = nd_allow_dynamic_lds((const void*)k_attention_lds<NF>, lds, &attr_done);
-        if (e != hipSuccess) return e;
-    }
-    // query splits: enough workgroups for >= 3 per CU when the problem allows, at least 2 waves each
-    static const int qs_env = getenv("ND_ATT_QS") ? atoi(getenv("ND_ATT_QS")) : 0;
-    int qs = qs_env > 0 ? qs_env : 1;
-    if (qs_env <= 0) while (qs < 4 && (long)B * heads * qs < 768 && (NF + qs) / (qs + 1) >= 2) ++qs;
-    if (qs > NF) qs = NF;
-    const int wpq = (NF + qs - 1) / qs;
-    hipLaunchKernelGGL((k_attention_lds<NF>), dim3(B * heads, (NF + wpq - 1) / wpq), dim3(wpq * 64), lds, st, qkv, out, B, N, heads);
-    return hipGetLastError();
-}
-
 // RING form (the default fp32 kernel): nd_attention.hip, a translation unit of its own (accumulators kept in VGPRs).
 hipError_t nd_launch_attention_ring(const float* qkv, float* out, int B, int N, int heads, hipStream_t st);
 
@@ -705,12 +474,8 @@ extern "C" int nd_attention(const float* qkv, float* out, int B, int N, int head
     if (B < 1 || heads < 1 || N < 1 || N > 16 * AT_MAXF) return nd_set_err(ND_ERR_ARG, "need 1 <= N <= %d", 16 * AT_MAXF);
     hipStream_t st = (hipStream_t)stream;
     const int nf = (N + 15) / 16;
-    static const int form = getenv("ND_ATT_FORM") ? atoi(getenv("ND_ATT_FORM")) : 2;   // 2 = 4-wave ring (default), 1 = whole K/V in LDS, 0 = K/V from L2 per wave
-    const dim3 grid((nf + 3) / 4, B * heads), block(256);
 #define AT_CASE(NFV) case NFV: if (dtype == ND_DTYPE_F16) HIP_CHECK((launch_attention_h<NFV>(qkv, out, B, N, heads, st)));  \
-                               else if (form == 2) HIP_CHECK(nd_launch_attention_ring(qkv, out, B, N, heads, st)); \
-                               else if (form == 1) HIP_CHECK((launch_attention_lds<NFV>(qkv, out, B, N, heads, st))); \
-                               else hipLaunchKernelGGL((k_attention_d64<NFV, 1, 2>), grid, block, 0, st, qkv, out, B, N, heads); break;
+                               else HIP_CHECK(nd_launch_attention_ring(qkv, out, B, N, heads, st)); break;
     switch (nf) {
         AT_CASE(1) AT_CASE(2) AT_CASE(3) AT_CASE(4) AT_CASE(5) AT_CASE(6) AT_CASE(7) AT_CASE(8)
         AT_CASE(9) AT_CASE(10) AT_CASE(11) AT_CASE(12) AT_CASE(13) AT_CASE(14) AT_CASE(15) AT_CASE(16)
