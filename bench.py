@@ -265,6 +265,9 @@ def main():
             except Exception:
                 traffic = None
         roof["traffic"] = traffic
+        # the same launches also issue K*2*M*F*F exact-f32 MFMA flop: at M = 32 rows that is 34 us of matrix-pipe time per launch,
+        # so the kernel sits against BOTH the stream and the f32 matrix pipe (PMC SQ_VALU_MFMA_BUSY 0.55, profiles/r02_pmc_mfma.csv)
+        roof["co_limit_mfma_frac"] = (K * 2.0 * M * F * F / (avg_us * 1e-6) / 1e12 / F32_MFMA_PEAK_TF) if (n_probe and args.dtype == "f32") else None
         roof["note"] = ("bytes delivered to the CUs per second: ~208 MB of the 2*K*F*F*4 weight bytes a step reads are kept resident in the "
                         "256 MiB Infinity Cache across steps (default-policy loads; the rest streams from HBM with nontemporal loads)")
         roof["traffic_source"] = ("profiles/traffic.json: rocprofv3 PMC (FETCH_SIZE x2 + WRITE_SIZE, separate passes) of this kernel at this "
