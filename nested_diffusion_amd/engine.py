@@ -69,7 +69,8 @@ class EnsembleEngine:
     # -- weights -----------------------------------------------------------------------------
     def load_member(self, k: int, state_dict: Dict[str, torch.Tensor]) -> None:
         """state_dict = ConditionalModel.state_dict() (checkpoint key 'noise_estimator',
-        classification_train_separately.py:689-690).  Shapes are checked strictly."""
+        classification_train_separately.py:689-690).  Shapes are checked strictly; lin1 may be [F, 2C] (include_guidance: True,
+        the shipped configs) or [F, C] (guidance=False)."""
         C_, D, H, F, T = self.C, self.D, self.H, self.F, self.T
         want = {"encoder_x.0.weight": (H, D), "encoder_x.3.weight": (H, H), "encoder_x.6.weight": (F, H),
                 "lin1.lin.weight": (F, 2 * C_), "lin2.lin.weight": (F, F), "lin3.lin.weight": (F, F),
@@ -82,6 +83,10 @@ class EnsembleEngine:
             if key not in state_dict:
                 raise KeyError(f"state_dict is missing '{key}'")
             t = self._dev(state_dict[key])
+            if key == "lin1.lin.weight" and tuple(t.shape) == (F, C_):
+                # member built with guidance=False: lin1 takes y_t alone (latent_model.py:157-158, 172).  The library's step
+                # head always reads [y_t, yhat]; zero weights on the yhat half add 0 * yhat = +-0 per term: same sums.
+                t = torch.cat([t, torch.zeros_like(t)], dim=1).contiguous()
             if key in want and tuple(t.shape) != want[key]:
                 raise ValueError(f"'{key}' has shape {tuple(t.shape)}, expected {want[key]}")
             held[key] = t

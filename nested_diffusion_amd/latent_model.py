@@ -47,8 +47,6 @@ class ConditionalModel(nn.Module):
         hidden_dim = config.model.hidden_dim
         if arch != "linear":
             raise NotImplementedError(f"arch '{arch}': only 'linear' (the shipped configs) is on the hot path")
-        if not guidance:
-            raise NotImplementedError("guidance=False: the shipped configs set include_guidance: True")
         self.guidance = guidance
         self.dims = (y_dim, data_dim, hidden_dim, feature_dim, config.diffusion.timesteps)
         self.max_batch, self.max_rows = max_batch, max_rows or max_batch
@@ -57,7 +55,7 @@ class ConditionalModel(nn.Module):
             nn.Linear(hidden_dim, hidden_dim), nn.BatchNorm1d(hidden_dim), nn.Softplus(),
             nn.Linear(hidden_dim, feature_dim))
         self.norm = nn.BatchNorm1d(feature_dim)
-        self.lin1 = ConditionalLinear(y_dim * 2, feature_dim, n_steps)
+        self.lin1 = ConditionalLinear(y_dim * 2 if guidance else y_dim, feature_dim, n_steps)   # latent_model.py:155-158
         self.unetnorm1 = nn.BatchNorm1d(feature_dim)
         self.lin2 = ConditionalLinear(feature_dim, feature_dim, n_steps)
         self.unetnorm2 = nn.BatchNorm1d(feature_dim)
@@ -84,7 +82,7 @@ class ConditionalModel(nn.Module):
             if self._engine is None or self._engine.device != dev:
                 self._engine = EnsembleEngine(C, D, H, F, T, n_members=1, max_batch=self.max_batch, max_rows=self.max_rows,
                                               device=dev)
-            self._engine.load_member(0, self.state_dict())
+            self._engine.load_member(0, self.state_dict())      # [F, C] lin1 of guidance=False is widened there
             self._engine_sig, self._enc_sig = sig, None
         return self._engine
 
@@ -98,10 +96,22 @@ class ConditionalModel(nn.Module):
 
     def forward(self, x, y, t, yhat=None):
         """eps_theta(x, y_t, t, yhat) -> [B, C] (latent_model.py:169-184)."""
-        if yhat is None:
+        if self.guidance and yhat is None:
             raise ValueError("guidance=True requires yhat")
-        t = torch.as_tensor(t).reshape(-1)
-        if t.numel() > 1 and not bool((t == t[0]).all()):
-            raise NotImplementedError("per-row timesteps: the inference path always passes one t (diffusion_utils.py:68)")
+        if not self.guidance:
+            yhat = torch.zeros_like(y)                          # ignored by the reference (latent_model.py:172): zero weights here
+        t = torch.as_tensor(t).reshape(-1).cpu()
+        if t.numel() not in (1, y.shape[0]):
+            raise ValueError(f"t must hold 1 or {y.shape[0]} timesteps, got {t.numel()}")
         self.encode(x)
-        return self.hip_engine().eps_theta(0, y, yhat, int(t[0]))
+        eng = self.hip_engine()
+        steps = torch.unique(t).tolist()
+        if len(steps) == 1:                                     # the inference path: one t for the batch (diffusion_utils.py:68)
+            return eng.eps_theta(0, y, yhat, int(steps[0]))
+        # per-row timesteps (the training-time call shape, gamma = embed(t) per row, latent_model.py:101-105): rows are
+        # independent, so evaluate the batch once per distinct t and keep each row from the pass of its own t
+        out = None
+        for step in steps:
+            e = eng.eps_theta(0, y, yhat, int(step))
+            out = e.clone() if out is None else torch.where((t == step).to(e.device)[:, None], e, out)
+        return out

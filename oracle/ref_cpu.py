@@ -233,24 +233,26 @@ def p_sample_t_1to0_given_eps(y: Tensor, y_T_mean: Tensor, eps_theta: Tensor, om
 
 def p_sample_loop(p: Dict[str, Tensor], x: Tensor, y_0_hat: Tensor, y_T_mean: Tensor, n_steps: int,
                   alphas: Tensor, omabs: Tensor, noise: Tensor, only_last_sample: bool = True,
-                  hoist: bool = True):
+                  hoist: bool = True, guidance: bool = True):
     """p_sample_loop (diffusion_utils.py:133-163) with the RNG draws supplied as
     ``noise[n_steps, B, C]`` in the reference's draw order: row 0 is the initial
     ``randn_like(y_T_mean)`` (:139), row i (i>=1) is the draw inside p_sample for
     t = n_steps - i (:67).  ``hoist=True`` evaluates the t-invariant encoder once
-    (bit-identical on CPU); ``hoist=False`` is the as-written cost model."""
+    (bit-identical on CPU); ``hoist=False`` is the as-written cost model.
+    ``guidance=False``: the model was built without guidance and ignores the y_0_hat it is handed (latent_model.py:157-158, 172)."""
     assert noise.shape[0] == n_steps
+    yh = y_0_hat if guidance else None
     xe = encoder_x(p, x) if hoist else None
     cur_y = noise[0] + y_T_mean                                     # :139-140
     seq = [cur_y]
     for i, t in enumerate(reversed(range(1, n_steps)), start=1):    # :145
         tt = torch.tensor([t])
         xe_t = xe if hoist else encoder_x(p, x)
-        eps = trunk(p, xe_t, cur_y, tt, y_0_hat)                    # :81
+        eps = trunk(p, xe_t, cur_y, tt, yh)                         # :81
         cur_y = p_sample_given_eps(cur_y, y_T_mean, eps, t, alphas, omabs, noise[i])
         seq.append(cur_y)
     xe_t = xe if hoist else encoder_x(p, x)
-    eps = trunk(p, xe_t, cur_y, torch.tensor([0]), y_0_hat)         # :103
+    eps = trunk(p, xe_t, cur_y, torch.tensor([0]), yh)              # :103
     y_0 = p_sample_t_1to0_given_eps(cur_y, y_T_mean, eps, omabs)    # :155
     if only_last_sample:
         return y_0

@@ -77,6 +77,39 @@ def test_module_and_p_sample_loop_dropin():
         model.train()(x, yhat, torch.tensor([0]), yhat)        # inference only
 
 
+def test_guidance_false_and_per_row_timesteps():
+    """The two call shapes of ConditionalModel.forward the inference loop never uses (latent_model.py:157-158: lin1 on y_t
+    alone; :101-105: gamma = embed(t) with one t PER ROW, the training-time call) against the oracle, and a whole reverse
+    loop of a guidance=False model."""
+    from nested_diffusion_amd import diffusion_utils as du
+    from nested_diffusion_amd.latent_model import ConditionalModel
+    D, H, Fd, C, T, B = 192, 64, 96, 3, 12, 7
+    g = torch.Generator().manual_seed(4)
+    x, y, yhat = torch.rand(B, D, generator=g), torch.randn(B, C, generator=g), torch.rand(B, C, generator=g)
+    t_rows = torch.tensor([0, 11, 3, 3, 7, 0, 9])          # the reference draws t in [0, timesteps) (:randint), so row T of the embedding is never read
+    a, s = ref_cpu.schedule_tables("linear", T, 1e-4, 0.02)
+    for guidance in (True, False):
+        p = ref_cpu.init_cond_model_params(D, H, Fd, C, T, guidance, seed=70 + guidance)
+        model = ConditionalModel(small_config(D, H, Fd, C, T, B), guidance=guidance, max_batch=8)
+        model.load_state_dict(p, strict=True)
+        model = model.to("cuda").eval()
+        ref = ref_cpu.cond_model_forward(p, x, y, t_rows, yhat if guidance else None)
+        got = model(x.cuda(), y.cuda(), t_rows.cuda(), yhat.cuda() if guidance else None)
+        assert (got.cpu() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item()), guidance
+        one = model(x.cuda(), y.cuda(), torch.tensor([5]), yhat.cuda())          # yhat handed over and ignored when guidance=False
+        ref1 = ref_cpu.cond_model_forward(p, x, y, torch.tensor([5]), yhat if guidance else None)
+        assert (one.cpu() - ref1).abs().max().item() < 2e-5 * max(1.0, ref1.abs().max().item()), guidance
+    with pytest.raises(ValueError):
+        model(x.cuda(), y.cuda(), torch.tensor([1, 2]), yhat.cuda())
+    # reverse loop of the guidance=False model: yhat is still the prior mean (diffusion_utils.py:139-140), not an input of eps_theta
+    noise = torch.randn(T, B, C, generator=g)
+    ref_seq = ref_cpu.p_sample_loop(p, x, yhat, yhat, T, a, s, noise, only_last_sample=False, guidance=False)
+    seq = du.p_sample_loop(model, x.cuda(), yhat.cuda(), yhat.cuda(), T, a.cuda(), s.cuda(), only_last_sample=False,
+                           noise=noise.cuda())
+    ref_t, got_t = torch.stack(ref_seq), torch.stack(seq).cpu()
+    assert (got_t - ref_t).abs().max().item() < 2e-5 * max(1.0, ref_t.abs().max().item())
+
+
 def test_runner_hot_path_vs_oracle():
     """Diffusion.predict_batch (test_atk :749-794) == oracle ensemble on identical weights and noise:
     class probabilities within 1e-3 (the north-star criterion), votes equal."""
