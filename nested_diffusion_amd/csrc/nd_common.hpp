@@ -173,6 +173,25 @@ struct SkinnyDesc {
     int keep;            // 1: this member's W is read with default-policy loads in an NT kernel (kept in the Infinity Cache across steps)
 };
 
+// Up to ND_INLINE_DESCS members' descriptors travel BY VALUE in the kernel arguments (table == nullptr): a workgroup then has its
+// operand pointers after one scalar load from the kernarg segment instead of a kernarg load followed by a dependent global load
+// of table[g] -- one memory round trip less before the first weight request of every launch.
+#define ND_INLINE_DESCS 8
+struct SkinnyInline { SkinnyDesc d[ND_INLINE_DESCS]; };
+
+// struct copy out of the constant address space (scalar loads when the address is wave-uniform), word by word: the implicit copy
+// constructor cannot bind an address-space-qualified source
+template <typename T>
+__device__ __forceinline__ T nd_ldc(const __attribute__((address_space(4))) void* p) {
+    static_assert(sizeof(T) % 4 == 0, "word-sized structs only");
+    T out;
+    const __attribute__((address_space(4))) uint32_t* w = (const __attribute__((address_space(4))) uint32_t*)p;
+    uint32_t* o = reinterpret_cast<uint32_t*>(&out);
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(T) / 4; ++i) o[i] = w[i];
+    return out;
+}
+
 // WORK DECOMPOSITION.  A workgroup never mixes members (it would have to stream two activation matrices and finishes
 // 40 % late: measured).  Each member's nfr = ceil(N/16) 16-column output fragments go to wpm = gridDim.x / nm workgroups:
 // base = nfr / wpm each, the first nfr % wpm of them one more.  NF (template) = the larger count; a workgroup holding
@@ -186,21 +205,25 @@ struct SkinnyDesc {
 // both operands).
 // H = 1: operands are frag32h (fp16), one v_mfma_f32_16x16x32_f16 per fragment pair and 32-column chunk.
 template <int MT, int NF, int WAVES, int U, int MODE, bool NT, int H = 0>
-__global__ __launch_bounds__(WAVES * 64) void k_skinny(SkinnyDesc d0, const SkinnyDesc* __restrict__ table, int nm,
+__global__ __launch_bounds__(WAVES * 64) void k_skinny(SkinnyInline di, const SkinnyDesc* __restrict__ table, int nm,
                                                        int M, int t, int cps) {
     const int tid = threadIdx.x, lane = tid & 63;
 #ifdef ND_WG_TIMING
     const long long dbg_t0 = wall_clock64();
 #endif
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: keeps stream addresses in SGPRs
-    const int K = table ? table[0].K : d0.K, N = table ? table[0].N : d0.N;
+    // both sources are read through the CONSTANT address space (scalar loads; a select between a kernarg and a generic pointer
+    // would turn every descriptor access into a flat vector load): `di` is the first kernel argument = kernarg offset 0
+    typedef const __attribute__((address_space(4))) char* nd_cbytes;
+    const nd_cbytes dsrc = table ? (nd_cbytes)(uintptr_t)table : (nd_cbytes)__builtin_amdgcn_kernarg_segment_ptr();
+    const int K = nd_ldc<SkinnyDesc>(dsrc).K, N = nd_ldc<SkinnyDesc>(dsrc).N;
     const int nch = H ? K >> 5 : K >> 4, nfr = (N + 15) >> 4, mtiles = (M + 15) >> 4;
     const int wpm = gridDim.x / nm;                               // workgroups per member
     const int g = blockIdx.x / wpm, j = blockIdx.x - g * wpm;     // member, workgroup inside the member
     const int base = nfr / wpm, rem = nfr - base * wpm;
     const int nact = base + (j < rem ? 1 : 0);                    // fragments this workgroup owns: NF or NF - 1
     const int fi0 = j * base + min(j, rem);                       // its first fragment inside the member
-    const SkinnyDesc d = table ? table[g] : d0;
+    const SkinnyDesc d = nd_ldc<SkinnyDesc>(dsrc + (size_t)g * sizeof(SkinnyDesc));
     const int c0 = MODE == 2 ? blockIdx.z * cps : 0;
     const int c1 = MODE == 2 ? min(c0 + cps, nch) : nch;
     const float* wp[NF];
@@ -628,9 +651,22 @@ static inline size_t nd_splitk_part_floats(int M, int K, int N, int nm = 1, int 
     return (size_t)L.S * (size_t)(((M + 15) / 16) * 16) * (size_t)(((N + 15) / 16) * 16);
 }
 
+// descs: HOST copies of the nm members' descriptors (nm <= ND_INLINE_DESCS): passed by value
+static inline hipError_t nd_launch_skinny_inline(const SkinnyLaunch& L, const SkinnyDesc* descs, int nm, int M, int t, hipStream_t st) {
+    int cps = L.cps;
+    SkinnyInline di{};
+    for (int g = 0; g < nm && g < ND_INLINE_DESCS; ++g) di.d[g] = descs[g];
+    const SkinnyDesc* table = nullptr;
+    void* args[] = {&di, &table, &nm, &M, &t, &cps};
+    return hipLaunchKernel(L.fn, L.grid, L.block, args, 0, st);
+}
+
+// d0: the descriptor of a single-member launch (table == nullptr, nm == 1), else ignored: table[0 .. nm) in device memory.
 static inline hipError_t nd_launch_skinny(const SkinnyLaunch& L, SkinnyDesc d0, const SkinnyDesc* table, int nm, int M, int t,
                                           hipStream_t st) {
     int cps = L.cps;
-    void* args[] = {&d0, &table, &nm, &M, &t, &cps};
+    SkinnyInline di{};
+    di.d[0] = d0;
+    void* args[] = {&di, &table, &nm, &M, &t, &cps};
     return hipLaunchKernel(L.fn, L.grid, L.block, args, 0, st);
 }

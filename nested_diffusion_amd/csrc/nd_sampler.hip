@@ -61,6 +61,7 @@ struct MemberDev {
 };
 
 #define ND_MAX_C 8
+struct MemberInline { MemberDev m[ND_INLINE_DESCS]; };   // by value in the kernel arguments (members == nullptr): see SkinnyInline
 
 // Pointers that come out of descriptor structs are generic to the compiler; loads through them become flat_load, which is
 // counted on vmcnt AND lgkmcnt and cannot be waited on selectively -- the step head's "tables in flight under the reduction"
@@ -147,9 +148,11 @@ __device__ __forceinline__ void nd_reduce_eps(const float* __restrict__ epart, i
 // Every thread computes y_t redundantly (C values), so nothing crosses threads after the reduce; the
 // table / xe / lin1 loads are issued before the reduction so their latency overlaps it.
 template <int C>
-__global__ __launch_bounds__(256) void k_step_head(const MemberDev* __restrict__ members, StepIO io, int mode, int i_step,
+__global__ __launch_bounds__(256) void k_step_head(MemberInline mi, const MemberDev* __restrict__ members, StepIO io, int mode, int i_step,
                                                    int t_prev, int t, int B, int M, int maxM, int F, int NT, int T) {
-    const MemberDev mb = members[blockIdx.z];
+    typedef const __attribute__((address_space(4))) char* nd_cbytes;           // scalar loads from either source (see k_skinny)
+    const MemberDev mb = nd_ldc<MemberDev>((members ? (nd_cbytes)(uintptr_t)members : (nd_cbytes)__builtin_amdgcn_kernarg_segment_ptr()) +
+                                           (size_t)blockIdx.z * sizeof(MemberDev));
     const int z = blockIdx.z, m = blockIdx.y, b = m % B, tid = threadIdx.x;
     __shared__ float red[4 * C];
     const int n = blockIdx.x * 1024 + tid * 4;
@@ -241,9 +244,11 @@ static void* head_fn(int C) {
 // eps_only: 0 = y_0 of the loop, 1 = eps output, 2 = one p_sample step from io.y_in with the draw in
 // io.noise (t = par_cur), 3 = p_sample_t_1to0 from io.y_in.
 template <int C>
-__global__ __launch_bounds__(64) void k_step_final(const MemberDev* __restrict__ members, StepIO io, int eps_only, int par_cur,
+__global__ __launch_bounds__(64) void k_step_final(MemberInline mi, const MemberDev* __restrict__ members, StepIO io, int eps_only, int par_cur,
                                                    int B, int M, int maxM, int NT, int T, float* eps_out, size_t eps_ms) {
-    const MemberDev mb = members[blockIdx.z];
+    typedef const __attribute__((address_space(4))) char* nd_cbytes;           // scalar loads from either source (see k_skinny)
+    const MemberDev mb = nd_ldc<MemberDev>((members ? (nd_cbytes)(uintptr_t)members : (nd_cbytes)__builtin_amdgcn_kernarg_segment_ptr()) +
+                                           (size_t)blockIdx.z * sizeof(MemberDev));
     const int z = blockIdx.z, m = blockIdx.x, b = m % B;
     __shared__ float red[C];
     float epsv[C];
@@ -341,6 +346,8 @@ struct nd_handle_s {
     std::vector<MemberHost> members;
     MemberDev* members_dev = nullptr;      // [K]
     SkinnyDesc* descs_dev = nullptr;       // [L_COUNT][K]
+    std::vector<SkinnyDesc> descs_host;    // the same table on the host: the step launches pass their rows by value (SkinnyInline)
+    std::vector<MemberDev> members_host;   // ... and the step head / final kernels theirs (MemberInline)
     SkinnyDesc* spk_dev = nullptr;         // [K]   encoder_x.0 as split-K partial sums (MODE 2)
     SplitKEpiDesc* spke_dev = nullptr;     // [K]
     float *alphas = nullptr, *omabs = nullptr;
@@ -552,8 +559,13 @@ extern "C" int nd_load_member(nd_handle h, int k, const nd_member_weights* w, vo
     // caller may release its raw weight tensors as soon as this function returns.
     HIP_CHECK(hipStreamSynchronize(st));
     HIP_CHECK(hipMemcpy(h->members_dev + k, &md, sizeof md, hipMemcpyHostToDevice));
-    for (int l = 0; l < L_COUNT; ++l)
+    h->members_host.resize(c.n_members);
+    h->descs_host.resize((size_t)L_COUNT * c.n_members);
+    h->members_host[k] = md;
+    for (int l = 0; l < L_COUNT; ++l) {
+        h->descs_host[(size_t)l * c.n_members + k] = ds[l];
         HIP_CHECK(hipMemcpy(h->descs_dev + (size_t)l * c.n_members + k, &ds[l], sizeof(SkinnyDesc), hipMemcpyHostToDevice));
+    }
     if (h->enc_splitk) {
         SkinnyDesc sd{h->xpack, m.w_enc0, nullptr, nullptr, nullptr, nullptr, m.splitk, D, H, C, ND_ACT_NONE, 0};
         SplitKEpiDesc se{m.splitk, m.sc0, m.sh0, m.e0, H, 0 /* S is a launch argument */, ND_ACT_SOFTPLUS, opk};
@@ -676,17 +688,19 @@ static int single_eval(nd_handle_s* h, int member, StepIO io, int t, int final_m
     const int K = c.n_members, F = c.feature_dim, C = c.y_dim, M = B * mc;
     {
         const MemberDev* mdev = h->members_dev + member;
+        MemberInline mi{};
         int mode = ND_HEAD_GIVEN, istep = 0, tprev = 0, tt = t, Bv = B, Mv = M, maxM = c.max_rows, Fv = F, NT = step_partials(h, M), Tn = c.n_steps;
-        void* ah[] = {&mdev, &io, &mode, &istep, &tprev, &tt, &Bv, &Mv, &maxM, &Fv, &NT, &Tn};
+        void* ah[] = {&mi, &mdev, &io, &mode, &istep, &tprev, &tt, &Bv, &Mv, &maxM, &Fv, &NT, &Tn};
         HIP_CHECK(hipLaunchKernel(head_fn(C), dim3((F + 1023) / 1024, M, 1), dim3(256), ah, 0, st));
     }
     HIP_CHECK(launch_step_block<0>(h, h->descs_dev + (size_t)L_LIN2 * K + member, M, t, 1, st));
     HIP_CHECK(launch_step_block<1>(h, h->descs_dev + (size_t)L_LIN3 * K + member, M, t, 1, st));
     {
         const MemberDev* mdev = h->members_dev + member;
+        MemberInline mi{};
         int fm = final_mode, tt = t, Bv = B, Mv = M, maxM = c.max_rows, NT = step_partials(h, M), Tn = c.n_steps;
         size_t ems = 0;
-        void* af[] = {&mdev, &io, &fm, &tt, &Bv, &Mv, &maxM, &NT, &Tn, &out, &ems};
+        void* af[] = {&mi, &mdev, &io, &fm, &tt, &Bv, &Mv, &maxM, &NT, &Tn, &out, &ems};
         HIP_CHECK(hipLaunchKernel(final_fn(C), dim3(M, 1, 1), dim3(64), af, 0, st));
     }
     HIP_CHECK(hipGetLastError());
@@ -753,9 +767,19 @@ struct Emitter {
 static hipError_t emit_loop(nd_handle_s* h, Emitter& em, int m0, int nm, StepIO io, int B, int mc, int T) {
     const nd_config& c = h->cfg;
     int K = c.n_members, F = c.feature_dim, C = c.y_dim, M = B * mc, maxM = c.max_rows, NT = step_partials(h, M), Tn = T;
-    const MemberDev* mdev = h->members_dev + m0;
+    // descriptor rows by value while they fit (nm <= ND_INLINE_DESCS), else through the device tables
+    const bool inl = nm <= ND_INLINE_DESCS;
+    const MemberDev* mdev = inl ? nullptr : h->members_dev + m0;
     const SkinnyDesc* t2 = h->descs_dev + (size_t)L_LIN2 * K + m0;
     const SkinnyDesc* t3 = h->descs_dev + (size_t)L_LIN3 * K + m0;
+    const SkinnyDesc *s2 = inl ? nullptr : t2, *s3 = inl ? nullptr : t3;     // k_skinny's table argument
+    MemberInline mi{};
+    SkinnyInline i2{}, i3{};
+    for (int g = 0; inl && g < nm; ++g) {
+        mi.m[g] = h->members_host[m0 + g];
+        i2.d[g] = h->descs_host[(size_t)L_LIN2 * K + m0 + g];
+        i3.d[g] = h->descs_host[(size_t)L_LIN3 * K + m0 + g];
+    }
     SkinnyDesc d0{};
     const dim3 ghead((F + 1023) / 1024, M, nm);
     const SkinnyLaunch L2 = nd_skinny_launch<0>(F, F, M, nm, h->half), L3 = nd_skinny_launch<1>(F, F, M, nm, h->half);
@@ -779,7 +803,7 @@ static hipError_t emit_loop(nd_handle_s* h, Emitter& em, int m0, int nm, StepIO 
         const bool probe = want > 0 && i >= 1 && probed < want && ((i - 1) % stride) == stride / 2;
         hipEvent_t* ev = probe ? &h->probe_events[5 * probed] : nullptr;
         if (probe) em.record(ev[0]);
-        void* ah[] = {&mdev, &io, &mode, &istep, &t_prev, &t, &B, &M, &maxM, &F, &NT, &Tn};
+        void* ah[] = {&mi, &mdev, &io, &mode, &istep, &t_prev, &t, &B, &M, &maxM, &F, &NT, &Tn};
         em.emit(head_fn(C), ghead, dim3(256), ah);
         if (probe) em.record(ev[1]);
         if (tp.use_tile) {
@@ -791,10 +815,10 @@ static hipError_t emit_loop(nd_handle_s* h, Emitter& em, int m0, int nm, StepIO 
             em.emit(nd_cond_gemm_kernel(1), tgrid, dim3(256), a3, nd_cond_gemm_dynlds());
             if (tp.rem > 0) em.emit(nd_cond_gemm_fixup_kernel(1), tfix, dim3(64), a3);
         } else {
-            void* a2[] = {&d0, &t2, &nm, &M, &t, &cps2};
+            void* a2[] = {&i2, &s2, &nm, &M, &t, &cps2};
             em.emit(L2.fn, L2.grid, L2.block, a2);
             if (probe) em.record(ev[2]);
-            void* a3[] = {&d0, &t3, &nm, &M, &t, &cps3};
+            void* a3[] = {&i3, &s3, &nm, &M, &t, &cps3};
             em.emit(L3.fn, L3.grid, L3.block, a3);
         }
         if (probe) { em.record(ev[3]); em.record(ev[4]); ++probed; }     // e3 -> e4 brackets nothing: the cost of a record node itself
@@ -803,7 +827,7 @@ static hipError_t emit_loop(nd_handle_s* h, Emitter& em, int m0, int nm, StepIO 
     int eps_only = 0, par_cur = (T - 1) & 1;
     float* eps_out = nullptr;
     size_t eps_ms = 0;
-    void* af[] = {&mdev, &io, &eps_only, &par_cur, &B, &M, &maxM, &NT, &Tn, &eps_out, &eps_ms};
+    void* af[] = {&mi, &mdev, &io, &eps_only, &par_cur, &B, &M, &maxM, &NT, &Tn, &eps_out, &eps_ms};
     em.emit(final_fn(C), dim3(M, 1, nm), dim3(64), af);
     return em.err;
 }
