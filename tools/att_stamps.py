@@ -32,3 +32,12 @@ for B in [int(v) for v in sys.argv[1:]] or [2, 16, 32]:
     print(f"B={B}: {nwg} workgroups; wave lifetime mean {span[act].mean():.0f} ticks, kernel span {(t[:, :, 13].max() - t[:, :, 0].min()):.0f} ticks")
     for i, n in enumerate(names):
         print(f"    {n:22s} {d[:, :, i][act].mean():9.0f}")
+    # when do workgroups start (first tile landed) and end, relative to the first start?  (cycles; by dispatch order)
+    t1, t13 = t[:, 0, 1], t[:, 0, 13]
+    z = t1.min()
+    q = torch.tensor([0.0, 0.1, 0.5, 0.9, 1.0], dtype=torch.float64)
+    for lo, hi in ((0, 768), (768, 1024), (1024, nwg)):
+        if lo >= nwg:
+            break
+        a, b = t1[lo:min(hi, nwg)] - z, t13[lo:min(hi, nwg)] - z
+        print(f"    workgroups {lo:4d}..{min(hi, nwg) - 1:4d}: first tile ready at {[int(v) for v in torch.quantile(a, q)]}, end at {[int(v) for v in torch.quantile(b, q)]} (min, 10 %, median, 90 %, max)")
