@@ -20,13 +20,14 @@ def rank_world() -> Tuple[int, int]:
     return 0, 1
 
 
-def init_from_env(backend: str = None) -> Tuple[int, int, int]:
+def init_from_env(backend: str = None, force: bool = False) -> Tuple[int, int, int]:
     """Initialise from torchrun's env (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).  Returns
-    (rank, local_rank, world).  No-op for single-process runs."""
+    (rank, local_rank, world).  No-op for single-process runs unless `force` (a one-rank group: lets a 1-GPU box run the
+    RCCL initialisation and collective of the production branch)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not td.is_initialized():
+    if (world > 1 or force) and not td.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -63,12 +64,13 @@ def shard_bounds(n: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + q + (1 if rank < r else 0)
 
 
-def all_gather_rows(local: torch.Tensor, n_total: int, world: int = None) -> torch.Tensor:
+def all_gather_rows(local: torch.Tensor, n_total: int, world: int = None, force_collective: bool = False) -> torch.Tensor:
     """Concatenate the ranks' row shards (dim 0) in rank order with one all_gather.  Shards may be
-    ragged by one row (shard_bounds); they are padded to the widest shard for the collective."""
+    ragged by one row (shard_bounds); they are padded to the widest shard for the collective.
+    force_collective: issue the collective even in a one-rank group (tests)."""
     rank, w = rank_world()
     world = w if world is None else world
-    if world == 1:
+    if world == 1 and not (force_collective and td.is_initialized()):
         return local
     q, r = divmod(n_total, world)
     widest = q + (1 if r else 0)

@@ -95,3 +95,37 @@ def test_two_ranks_sharded_batch_equals_full_batch(tmp_path):
         res = torch.load(os.path.join(str(tmp_path), f"r{r}.pt"))
         print(res)
         assert res["ok"], res
+
+
+def _rccl_one_rank(port, out_path):
+    """dist.py's production branch on whatever one GPU offers: backend 'nccl' (= RCCL), communicator bound to the device,
+    all_gather_into_tensor on device tensors -- in a one-rank group."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    import torch.distributed as td
+    from nested_diffusion_amd import dist as nd_dist
+    rank, local, world = nd_dist.init_from_env(backend="nccl", force=True)
+    assert (rank, local, world) == (0, 0, 1) and td.get_backend() == "nccl"
+    x = torch.arange(7 * 2, dtype=torch.float32, device="cuda:0").reshape(7, 2)
+    got = nd_dist.all_gather_rows(x, 7, force_collective=True)
+    td.barrier(device_ids=[0])
+    torch.cuda.synchronize()
+    ok = got.is_cuda and torch.equal(got, x)
+    nd_dist.shutdown()
+    with open(out_path, "w") as f:
+        f.write("ok" if ok else "mismatch")
+
+
+def test_rccl_initialises_and_gathers_on_one_rank(tmp_path):
+    """The builder's boxes have one GPU, so the two-rank test above gathers over gloo there.  This one makes sure the RCCL
+    branch itself (init_process_group('nccl', device_id=...) + all_gather_into_tensor on HBM tensors) has run on the hardware."""
+    out = tmp_path / "rccl.txt"
+    ctx = mp.get_context("spawn")
+    p = ctx.Process(target=_rccl_one_rank, args=(_free_port(), str(out)))
+    p.start()
+    p.join(180)
+    if p.is_alive():
+        p.kill()
+        p.join()
+        pytest.fail("RCCL one-rank group did not finish in 180 s")
+    assert p.exitcode == 0
+    assert out.read_text() == "ok"
