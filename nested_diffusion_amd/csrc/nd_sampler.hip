@@ -28,7 +28,7 @@ extern "C" int nd_debug_set_wg_times(void* dev_ptr) {
     return hipMemcpyToSymbol(HIP_SYMBOL(nd_dbg_times), &dev_ptr, sizeof dev_ptr) == hipSuccess ? 0 : -1;
 }
 #endif
-extern "C" const char* nd_version(void) { return "libnd_hip gfx950 f32-mfma r1"; }
+extern "C" const char* nd_version(void) { return "libnd_hip gfx950 f32-mfma r2"; }
 int nd_set_err(int code, const char* fmt, ...) {
     char buf[512];
     va_list ap;
