@@ -7,7 +7,7 @@
 // RING form (the default fp32 kernel).  A workgroup is FOUR waves -- one per SIMD -- owning up to four 16-row query fragments
 // of one (image, head): ceil(NF/4) workgroups per head (NF = 13 at N = 196: 4 + 3 + 3 + 3 fragments), 1536 workgroups at
 // B = 32 x 12 heads.  K and then V pass through a two-slot LDS ring as 2 NT tiles K0 .. K(NT-1), V0 .. V(NT-1) of TF = ceil(NF/NT)
-// key fragments (NT = 3, TF = 5 at NF = 13: 40 KiB of LDS, three workgroups resident per CU), brought by LDS-DMA
+// key fragments (NT = 3, TF = 5 at NF = 13: 40 KiB of LDS, four workgroups resident per CU: 160 KiB exactly, and 110 VGPRs allow 4 waves per SIMD), brought by LDS-DMA
 // (global_load_lds_dwordx4: one 1 KiB piece = 4 key rows per wave instruction, no VGPR round trip).  Tile t + 2 is requested as
 // soon as tile t has been consumed, so every tile but the first has a whole compute phase to land:
 //     DMA K0, K1 | S += K0 q | DMA K2 | S += K1 q | DMA V0 | S += K2 q | DMA V1 | softmax | O += P V0 | DMA V2 | O += P V1 | O += P V2
