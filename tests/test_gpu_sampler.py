@@ -122,6 +122,33 @@ def test_mc_trials_and_members_batched():
     assert torch.equal(y1[0], y0[1])
 
 
+def test_more_members_than_inline_descriptors():
+    """Up to 8 members' descriptors travel by value in the kernel arguments; a launch over more members reads them from the
+    device tables instead (nd_sampler.hip emit_loop).  K = 11 in one graph, against the oracle member by member, graph == eager,
+    and a sub-range of 3 members (the by-value form) reproduces its slice bitwise."""
+    from nested_diffusion_amd.engine import EnsembleEngine
+    D, H, Fd, C, T, B, K = 64, 48, 80, 2, 5, 6, 11
+    members = [ref_cpu.init_cond_model_params(D, H, Fd, C, T, True, seed=300 + k) for k in range(K)]
+    eng = EnsembleEngine(C, D, H, Fd, T, n_members=K, max_batch=B)
+    for k in range(K):
+        eng.load_member(k, members[k])
+    alphas, omabs = ref_cpu.schedule_tables("linear", T, 1e-4, 0.02)
+    eng.set_schedule(alphas, omabs)
+    g = torch.Generator().manual_seed(8)
+    x = torch.rand(B, D, generator=g)
+    eng.encode(x)
+    yhat = torch.softmax(torch.randn(K, B, C, generator=g), -1)
+    noise = torch.randn(K, T, B, C, generator=g)
+    y0 = eng.sample(yhat.cuda(), yhat.cuda(), noise.cuda()).cpu()
+    y0_eager = eng.sample(yhat.cuda(), yhat.cuda(), noise.cuda(), use_graph=False).cpu()
+    assert torch.equal(y0, y0_eager)
+    for k in range(K):
+        ref = ref_cpu.p_sample_loop(members[k], x, yhat[k], yhat[k], T, alphas, omabs, noise[k])
+        assert (y0[k] - ref).abs().max() < 5e-5 * max(1.0, ref.abs().max()), k
+    sub = eng.sample(yhat[4:7].cuda(), yhat[4:7].cuda(), noise[4:7].cuda(), member0=4, n_members=3).cpu()
+    assert torch.equal(sub, y0[4:7])
+
+
 def test_error_paths():
     from nested_diffusion_amd import _lib
     from nested_diffusion_amd.engine import EnsembleEngine
