@@ -192,13 +192,15 @@ def test_reference_default_batch_70_and_row_groups():
         assert (y0[j * B:(j + 1) * B] - ref).abs().max() < 5e-5 * max(1.0, ref.abs().max())
 
 
-@pytest.mark.parametrize("K,Fd", [(3, 3200), (5, 1376), (2, 4112)])
-def test_members_with_uneven_fragment_dealing(K, Fd):
+@pytest.mark.parametrize("K,Fd,C", [(3, 3200, 2), (5, 1376, 2), (2, 4112, 2), (3, 3200, 7), (5, 4096, 5)])
+def test_members_with_uneven_fragment_dealing(K, Fd, C):
     """Multi-member launches whose fragments do not divide evenly over a member's workgroups: F = 3200 with 3 members gives
     85 workgroups per member, 30 of them with 3 fragments and 55 with 2; F = 1376 with 5 members 51 workgroups with 2 or 1;
-    F = 4112 with 2 members 128 workgroups with 3 or 2 -- the NF / NF-1 forms of k_skinny side by side in one launch."""
+    F = 4112 with 2 members 128 workgroups with 3 or 2 -- the NF / NF-1 forms of k_skinny side by side in one launch.
+    C = 7 / 5 classes with 3 / 6 fragments per workgroup: more lin4 entries (fragments x C x 16) than threads, the form of the
+    lin3 + lin4 epilogue that fetches them after the main loop, at the headline's dealing (5 members x 51 workgroups, F = 4096)."""
     from nested_diffusion_amd.engine import EnsembleEngine
-    D, H, C, T, B = 64, 48, 2, 3, 6
+    D, H, T, B = 64, 48, 3, 6
     ps = [ref_cpu.init_cond_model_params(D, H, Fd, C, T, True, seed=170 + k) for k in range(K)]
     eng = EnsembleEngine(C, D, H, Fd, T, n_members=K, max_batch=B)
     for k, p in enumerate(ps):
@@ -269,14 +271,14 @@ def test_large_m_row_groups(B, mc, F_, C_):
     assert (eps - ref).abs().max() < 5e-5 * max(1.0, ref.abs().max())
 
 
-@pytest.mark.parametrize("B,mc,K", [(32, 20, 5), (70, 20, 2), (33, 5, 1)])
-def test_reference_default_mc20_rows_at_feature_dim_4096(B, mc, K):
+@pytest.mark.parametrize("B,mc,K,C_", [(32, 20, 5, 2), (70, 20, 2, 2), (33, 5, 1, 2), (16, 9, 2, 5)])
+def test_reference_default_mc20_rows_at_feature_dim_4096(B, mc, K, C_):
     """The reference's own operating point: mc_trials = 20 (classification_train_separately.py:770-771) x batch 32 / 70
     (configs/chest_x_ray.yml:66) -> M = 640 / 1400 rows per member through lin2 / lin3 at F = 4096 -- the LDS-tiled
     k_cond_gemm (M > 128), incl. its k-split tail + fixup (K = 5, M = 640: 800 tiles = 768 whole + 32 cut 8 ways) and a ragged
     last row tile (M = 165).  y_0 of every (member, trial) vs the oracle; graph == eager bitwise."""
     from nested_diffusion_amd.engine import EnsembleEngine
-    D, H, F_, C_, T = 64, 64, 4096, 2, 3
+    D, H, F_, T = 64, 64, 4096, 3
     ps = [ref_cpu.init_cond_model_params(D, H, F_, C_, T, True, seed=300 + k) for k in range(K)]
     eng = EnsembleEngine(C_, D, H, F_, T, n_members=K, max_batch=B, max_rows=B * mc)
     plan = eng.step_plan(B * mc)
