@@ -8,7 +8,10 @@ One "step" = one pass of the WHOLE hot path over one batch, inputs already resid
   -> K x T reverse-diffusion steps (one hipGraph) -> convert_to_prob / mean / vote (-> RCCL all-gather for N>1).
 value = N * B*K*mc*T * steps / wall time (weak scaling: per-GPU batch fixed, no data-path collective).
 
-  python bench.py [--gpus N --steps K --warmup W]      (N>1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py [--gpus N --steps K --warmup W]
+N > 1: either launched by torch.distributed.run (one rank per GPU; RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the env), or
+invoked plainly -- the parent then starts the N ranks itself as child processes BEFORE it has touched the GPU, relays rank 0's
+line and exits non-zero if any rank did (launch_ranks below).
 Prints ONE JSON line on rank 0 with `roofline` (dominant kernel, HIP-event timed inside the run) and
 `cpu_baseline` (the CPU oracle in as-written mode on a bounded sample; rank 0, N=1 only).
 """
@@ -48,7 +51,9 @@ def build_runner(args, device):
              testing=ns(batch_size=args.batch))
     vit = VisionTransformer(synthetic.vit_state(seed=SEED_VIT, device=device), 12, device, dtype=args.dtype)
     mlps = [Classifier(synthetic.classifier_state(196 * 768, seed=SEED_MLP + k, device=device), device, dtype=args.dtype) for k in range(K)]
-    states = [synthetic.cond_model_state(D, H, F, C, T, seed=SEED_MEMBER + k, device=device) for k in range(K)]
+    # long schedules (T >= 500, BASELINE configs[4]): members with the denoiser-structured init, whose chains stay O(1) like a
+    # trained estimator's (synthetic.make_denoiser); a random eps_theta amplifies y_T by 1/sqrt(abar_T) ~ 160 at T = 1000
+    states = [synthetic.cond_model_state(D, H, F, C, T, seed=SEED_MEMBER + k, device=device, denoiser=T >= 500) for k in range(K)]
     runner = Diffusion(ns(seed=1234, mc_trials=args.mc, fp16=args.dtype == "f16"), cfg, device=device,
                        conditioner=GuidingConditioner(vit, mlps), noise_estimator_states=states)
     runner.load_noise_estimators(max_batch=args.batch, mc_trials=args.mc)
@@ -62,7 +67,7 @@ def host_copies(args, device):
     cpu = lambda sd: {k: v.cpu() for k, v in sd.items()}
     vit = cpu(synthetic.vit_state(seed=SEED_VIT, device=device))
     mlps = [cpu(synthetic.classifier_state(196 * 768, seed=SEED_MLP + k, device=device)) for k in range(K)]
-    members = [cpu(synthetic.cond_model_state(D, H, F, C, T, seed=SEED_MEMBER + k, device=device)) for k in range(K)]
+    members = [cpu(synthetic.cond_model_state(D, H, F, C, T, seed=SEED_MEMBER + k, device=device, denoiser=T >= 500)) for k in range(K)]
     return vit, mlps, members
 
 
@@ -148,6 +153,45 @@ def cpu_baseline(members_cpu, vit_cpu, mlps_cpu, images_cpu, out_gpu, noise, T_f
                       f"{T_full} steps with the encoder evaluated once per member, {t_samp:.1f} s"}
 
 
+def launch_ranks(n: int, argv) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* in their environment, one GPU each), let rank 0 print the JSON line on the inherited stdout, and return non-zero
+    if any rank failed (the others are then terminated instead of waiting in a collective).  The parent has made NO GPU call
+    when it gets here (`torch.cuda.device_count()` does not initialise the runtime on this image) and makes none afterwards:
+    a process that has initialised the GPU must not exec or fork workers."""
+    import socket
+    import subprocess
+    n_dev = torch.cuda.device_count()
+    shared = os.environ.get("ND_DIST_BACKEND", "") == "gloo"      # rehearsal: ranks share devices, collective over gloo
+    if n_dev < 1:
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    if n_dev < n and not shared:
+        raise SystemExit(f"--gpus {n} but only {n_dev} GPU(s) visible (ND_DIST_BACKEND=gloo lets ranks share a device for rehearsal)")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env))
+    rc = 0
+    live = list(procs)
+    while live:
+        for p in list(live):
+            try:
+                code = p.wait(timeout=0.5)
+            except subprocess.TimeoutExpired:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                for q in live:                      # exactly the children started above
+                    q.terminate()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -164,11 +208,13 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     from nested_diffusion_amd import dist as nd_dist
     rank, local, world = nd_dist.init_from_env()
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    n_ranks_seen = torch.distributed.get_world_size() if world > 1 else 1
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local)
@@ -299,7 +345,8 @@ def main():
                              "~3 us dispatch gap of its node (rocprofv3 begin->end durations in profiles/ are that much shorter)"}
     line = {
         "metric": "denoising-steps*images/sec (K=5,T=100,224^2)", "value": value, "unit": "denoising-step*images/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+        "n_gpus": world, "n_ranks_seen": n_ranks_seen,
+        "dist_backend": torch.distributed.get_backend() if world > 1 else None, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32" if args.dtype == "f32" else "f16 operands / f32 accumulate (secondary mode, not the reference's arithmetic)",
         "data": "synthetic",

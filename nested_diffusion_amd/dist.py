@@ -33,15 +33,18 @@ def init_from_env(backend: str = None, force: bool = False) -> Tuple[int, int, i
         if backend is None:
             # ND_DIST_BACKEND=gloo: rehearsal of the N > 1 path on a box with fewer GPUs than ranks (the ranks then share devices)
             backend = os.environ.get("ND_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
-        if torch.cuda.is_available():
-            local = local % max(torch.cuda.device_count(), 1)
+        n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
         if backend == "nccl":
+            # one rank per GPU: two ranks on one device make RCCL fail with a duplicate-GPU error (or hang)
+            if local >= n_dev:
+                raise RuntimeError(f"LOCAL_RANK={local} but only {n_dev} GPU(s) are visible: the nccl (RCCL) backend needs one "
+                                   "device per rank (ND_DIST_BACKEND=gloo lets ranks share a device for rehearsal)")
             torch.cuda.set_device(local)
             td.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
         else:
+            if n_dev:
+                local = local % n_dev            # rehearsal only: more ranks than devices share them
             td.init_process_group(backend, rank=rank, world_size=world)
-    elif torch.cuda.is_available():
-        local = local % max(torch.cuda.device_count(), 1)
     return rank, local, world
 
 

@@ -9,8 +9,9 @@ from typing import Dict
 import torch
 
 
-def cond_model_state(data_dim: int, hidden: int, feature: int, y_dim: int, n_steps: int, seed: int, device="cuda"
-                     ) -> Dict[str, torch.Tensor]:
+def cond_model_state(data_dim: int, hidden: int, feature: int, y_dim: int, n_steps: int, seed: int, device="cuda",
+                     denoiser: bool = False) -> Dict[str, torch.Tensor]:
+    """denoiser=True: see make_denoiser (long schedules, T = 1000: keeps the synthetic chain O(1) like a trained model's)."""
     g = torch.Generator(device=device).manual_seed(seed)
     p: Dict[str, torch.Tensor] = {}
 
@@ -37,7 +38,50 @@ def cond_model_state(data_dim: int, hidden: int, feature: int, y_dim: int, n_ste
         p[name + ".embed.weight"] = torch.rand(n_steps + 1, feature, generator=g, device=device)
         bn("unetnorm" + name[-1], feature)
     lin("lin4", feature, y_dim)
+    if denoiser:
+        make_denoiser(p, y_dim, n_steps)
     return p
+
+
+def make_denoiser(p: Dict[str, torch.Tensor], y_dim: int, n_steps: int, gain: float = 0.7, beta_start: float = 1e-4,
+                  beta_end: float = 0.02) -> None:
+    """Give a random ConditionalModel state_dict (in place) the behaviour of a TRAINED noise estimator:
+    eps_theta(y_t, t) = gain * (y_t - yhat) / sqrt(1 - abar_t) + (what the random features contribute).  A random-weight eps_theta
+    ignores the noise it should predict, so its reverse chain multiplies y_T by 1/sqrt(abar_T) (~160 at T = 1000, linear
+    schedule) and the samples leave the range where convert_to_prob means anything; with this signal path the chain is
+    contractive and |y_t| stays O(1).  The first 2C features of each layer are +/- pairs: lin1 emits +/-(y - yhat) with the
+    per-timestep gain 1/sqrt(1 - abar_t) in its embedding rows (latent_model.py:101-105), lin2 / lin3 / lin4 take pair
+    differences -- exactly linear since softplus(p) - softplus(-p) = p -- and xe is 1 on those features.  All other features
+    stay random.  Same construction as the oracle's initialiser that golden fixture `sampler_s4` was generated with."""
+    from .diffusion_utils import make_beta_schedule
+    C, S = y_dim, 2 * y_dim
+    dev = p["lin4.weight"].device
+    betas = make_beta_schedule(schedule="linear", num_timesteps=n_steps, start=beta_start, end=beta_end).float()
+    omabs = torch.sqrt(1 - (1.0 - betas).cumprod(dim=0)).to(dev)
+
+    def bn_identity(name, shift=0.0):
+        p[name + ".weight"][:S] = 1.0
+        p[name + ".bias"][:S] = shift
+        p[name + ".running_mean"][:S] = 0.0
+        p[name + ".running_var"][:S] = 1.0
+    p["encoder_x.6.weight"][:S] = 0.0
+    p["encoder_x.6.bias"][:S] = 0.0
+    bn_identity("norm", 1.0)
+    eye = torch.eye(C, device=dev)
+    w1 = torch.cat([eye, -eye], dim=1)                                   # row c: y_c - yhat_c
+    p["lin1.lin.weight"][:S] = torch.cat([w1, -w1], dim=0)
+    p["lin1.lin.bias"][:S] = 0.0
+    p["lin1.embed.weight"][:n_steps, :S] = (1.0 / omabs)[:, None]
+    p["lin1.embed.weight"][n_steps, :S] = 1.0
+    bn_identity("unetnorm1")
+    for name in ("lin2", "lin3"):
+        w = p[name + ".lin.weight"]
+        w[:S] = 0.0
+        w[:S, :S] = torch.cat([w1, -w1], dim=0)                          # [[I, -I], [-I, I]]
+        p[name + ".lin.bias"][:S] = 0.0
+        p[name + ".embed.weight"][:, :S] = 1.0
+        bn_identity("unetnorm" + name[-1])
+    p["lin4.weight"][:, :S] = gain * w1
 
 
 def classifier_state(in_features: int, seed: int, widths=(4096, 2048, 128), num_classes: int = 2, device="cuda"):

@@ -88,10 +88,10 @@ def make_config(D, H, Fd, C, T, dataset="ChestXRay"):
               data=ns(num_classes=C, dataset=dataset))
 
 
-def build_ref_model(lm, D, H, Fd, C, T, seed):
+def build_ref_model(lm, D, H, Fd, C, T, seed, denoiser=False):
     cfg = make_config(D, H, Fd, C, T)
     model = lm.ConditionalModel(cfg, guidance=True)
-    params = ref_cpu.init_cond_model_params(D, H, Fd, C, T, True, seed=seed)
+    params = ref_cpu.init_cond_model_params(D, H, Fd, C, T, True, seed=seed, denoiser=denoiser)
     missing = model.load_state_dict(params, strict=True)
     model.eval()
     return model, params
@@ -125,16 +125,19 @@ def run_ref_loop(du, model, x, yhat, T, alphas, omabs, seed):
     return noise, torch.stack(seq)
 
 
-def gen_sampler_small(du, lm):
+def gen_sampler_small(du, lm, only=None):
     """Small/medium-dim ConditionalModel: whole state_dict + every intermediate y_t."""
     cases = [  # name, D, H, F, C, T, B, seed
         ("s0", 48, 64, 64, 2, 10, 3, 11),
         ("s1", 192, 128, 128, 2, 100, 32, 12),
         ("s2", 96, 64, 80, 3, 25, 1, 13),        # C=3, B=1, F not a power of two
-        ("s3", 160, 96, 256, 2, 1000, 5, 14),    # T=1000: 1/sqrt(abar) amplification
+        ("s3", 160, 96, 256, 2, 1000, 5, 14),    # T=1000: 1/sqrt(abar) amplification (random weights: expansive chain)
+        ("s4", 160, 96, 128, 2, 1000, 5, 15),    # T=1000 with the denoiser-structured init: contractive chain, |y_t| = O(1)
     ]
     for name, D, H, Fd, C, T, B, seed in cases:
-        model, params = build_ref_model(lm, D, H, Fd, C, T, seed)
+        if only and name not in only:
+            continue
+        model, params = build_ref_model(lm, D, H, Fd, C, T, seed, denoiser=(name == "s4"))
         g = torch.Generator().manual_seed(seed + 100)
         x = torch.rand(B, D, generator=g)
         yhat = torch.softmax(torch.randn(B, C, generator=g), dim=1)
@@ -260,10 +263,14 @@ def gen_perturb(runner):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-full", action="store_true")
+    ap.add_argument("--only", nargs="*", default=None, help="regenerate only these sampler cases (e.g. s4) and nothing else")
     a = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     du, lm, ref_mlp = import_reference()
+    if a.only:
+        gen_sampler_small(du, lm, only=set(a.only))
+        return
     gen_schedule(du)
     gen_sampler_small(du, lm)
     try:

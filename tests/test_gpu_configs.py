@@ -1,0 +1,162 @@
+"""BASELINE.json configs[3] and configs[4] run as their own workloads at CONFIG DIMS (D = 150528, F = H = 4096, ViT-B/16 prefix,
+five 150528-wide mapping MLPs), plus bench.py's self-launched multi-rank mode.
+
+configs[3]  "K=5, T=100, batch=256, members x batch sharded over 8 GPUs (32 per GPU), one all-gather": the per-rank workload is
+            run by TWO ranks on a global batch of 64 (32 rows per rank, exactly what each of the 8 ranks sees); the gathered class
+            probabilities must equal the one-process run on the same 64 images with the same --seed.  With >= 2 GPUs the ranks
+            take one device each and gather over RCCL; on a one-GPU box they share cuda:0 and gather over gloo.
+configs[4]  "ISICSkinCancer, K=5, T=1000, fp16": --fp16 at config dims, B = 32: hipGraph == eager, deterministic, and class
+            probabilities within a stated bound of the fp32 HIP path and of the CPU oracle on EVERY row.
+Reference anchors: diffusion/main.py:272-275 (single device), classification_train_separately.py:749-794 (hot loop),
+configs/isic_skin_cancer.yml (timesteps 1000)."""
+import argparse
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from oracle import ref_cpu
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORKER = os.path.join(ROOT, "tests", "_rank_worker.py")
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _run_ranks(world, out, backend, extra=()):
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        if world > 1:
+            env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), ND_DIST_BACKEND=backend)
+        else:
+            for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "ND_DIST_BACKEND"):
+                env.pop(k, None)
+        procs.append(subprocess.Popen([sys.executable, WORKER, "--out", out, *extra], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    logs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=900)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            pytest.fail(f"world-{world} run did not finish in 900 s")
+        logs.append(o)
+    for p, o in zip(procs, logs):
+        assert p.returncode == 0, o[-3000:]
+
+
+def test_config3_two_ranks_at_config_dims_equal_one_process(tmp_path):
+    torch.cuda.empty_cache()
+    backend = "nccl" if torch.cuda.device_count() >= 2 else "gloo"
+    one, two = str(tmp_path / "w1.pt"), str(tmp_path / "w2.pt")
+    _run_ranks(1, one, backend)
+    _run_ranks(2, two, backend)
+    a, b = torch.load(one), torch.load(two)
+    assert a["world"] == 1 and b["world"] == 2 and b["backend"] == backend
+    assert a["rows_per_rank"] == 64 and b["rows_per_rank"] == 32          # 32 rows per rank: configs[3]'s per-GPU shard
+    err = float((a["prob"] - b["prob"]).abs().max())
+    print(f"configs[3] per-rank workload, 2 ranks x 32 vs 1 x 64 at config dims ({backend}): max |class-prob delta| = {err:.2e}")
+    assert a["prob"].shape == b["prob"].shape == (64, 2)
+    # the 64-row and the 32-row launches deal the k-chunks to the waves differently: fp32 summation order only
+    assert err <= 2e-6, err
+    assert a["accuracy"] == b["accuracy"]
+
+
+def test_bench_gpus2_launches_its_own_ranks():
+    """`python bench.py --gpus 2` invoked PLAINLY (no torchrun): the parent starts both ranks before touching the GPU and
+    relays rank 0's single JSON line.  Ranks share cuda:0 over gloo when the box has one GPU."""
+    torch.cuda.empty_cache()
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    if torch.cuda.device_count() < 2:
+        env["ND_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["n_ranks_seen"] == 2
+    assert line["value"] > 0 and line["config"]["global_batch"] == 64 and line["scaling"] == "weak"
+    assert line["dist_backend"] == ("gloo" if torch.cuda.device_count() < 2 else "nccl")
+    print("bench --gpus 2:", line["value"], "step*img/s,", line["ms_per_step"], "ms/step,", line["dist_backend"])
+
+
+def test_bench_refuses_more_ranks_than_gpus_on_rccl():
+    """Without the gloo rehearsal switch a plain --gpus N with N > visible devices must fail before any rank starts."""
+    n = torch.cuda.device_count() + 1
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "ND_DIST_BACKEND")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "visible" in (r.stderr + r.stdout)
+
+
+def test_config4_isic_fp16_t1000_at_config_dims():
+    from nested_diffusion_amd import synthetic
+    from nested_diffusion_amd.mapping import Classifier, GuidingConditioner, VisionTransformer
+    from nested_diffusion_amd.runner import Diffusion
+    torch.cuda.empty_cache()
+    ns = argparse.Namespace
+    dev = "cuda"
+    D, H, F, C, T, K, B = 3 * 224 * 224, 4096, 4096, 2, 1000, 5, 32
+    cfg = ns(data=ns(dataset="ISICSkinCancer", num_classes=C), model=ns(data_dim=D, hidden_dim=H, feature_dim=F, arch="linear"),
+             diffusion=ns(timesteps=T, beta_schedule="linear", beta_start=1e-4, beta_end=0.02, aux_cls=ns(arch="sevit"),
+                          trained_aux_cls_ckpt_path="", trained_diffusion_ckpt_path=[[]], include_guidance=True),
+             testing=ns(batch_size=B))
+    vit_sd = synthetic.vit_state(seed=7, device=dev)
+    mlp_sd = [synthetic.classifier_state(196 * 768, seed=2000 + k, device=dev) for k in range(K)]
+    g = torch.Generator().manual_seed(99)
+    x = torch.rand(B, 3, 224, 224, generator=g).cuda()
+    noise = torch.randn(K, T, B, C, generator=g)
+    nz = noise.cuda()
+    outs = {}
+    member0_cpu = None
+    for mode in ("f16", "f32"):
+        # members with the denoiser-structured init (contractive chains like a trained estimator's; golden s4 pins it)
+        states = [synthetic.cond_model_state(D, H, F, C, T, seed=1000 + k, device=dev, denoiser=True) for k in range(K)]
+        if mode == "f32":
+            member0_cpu = {k: v.cpu() for k, v in states[0].items()}
+        cond = GuidingConditioner(VisionTransformer(vit_sd, 12, dev, dtype=mode), [Classifier(m, dev, dtype=mode) for m in mlp_sd])
+        runner = Diffusion(ns(seed=1, mc_trials=1, fp16=(mode == "f16")), cfg, device=dev, conditioner=cond, noise_estimator_states=states)
+        del states
+        assert runner.temperature == 0.3162 and runner.operand_dtype == mode
+        runner.load_noise_estimators(max_batch=B, mc_trials=1)
+        out = runner.predict_batch(x, noise=nz)
+        again = runner.predict_batch(x, noise=nz)
+        assert torch.equal(out["samples"], again["samples"]) and torch.equal(out["prob"], again["prob"])      # deterministic
+        if mode == "f16":
+            eng = runner.engine
+            eager = eng.sample(out["yhat"], out["yhat"], nz, mc=1, T=T, use_graph=False)
+            assert torch.equal(eager.reshape(K, B, C), out["samples"])                                          # graph == eager
+        outs[mode] = {k: v.cpu() for k, v in out.items()}
+        del runner, cond
+        torch.cuda.empty_cache()
+    s16, s32 = outs["f16"]["samples"], outs["f32"]["samples"]
+    assert float(s32.abs().max()) < 8.0 and float(s16.abs().max()) < 8.0                                       # tame: all rows count
+    d_y0 = float((s16 - s32).abs().max())
+    d_pr = float((outs["f16"]["prob"] - outs["f32"]["prob"]).abs().max())
+    # fp32 HIP path vs the CPU oracle at T = 1000, config dims, member 0 (1000 steps x 1 GFLOP on the host)
+    alphas, omabs = ref_cpu.schedule_tables("linear", T, 1e-4, 0.02)
+    yhat0 = outs["f32"]["yhat"][0]
+    ref0 = ref_cpu.p_sample_loop(member0_cpu, x.cpu().flatten(1), yhat0, yhat0, T, alphas, omabs, noise[0], True, hoist=True)
+    d_cpu = float((s32[0] - ref0).abs().max())
+    p_cpu = float((ref_cpu.convert_to_prob(s32[0], 0.3162) - ref_cpu.convert_to_prob(ref0, 0.3162)).abs().max())
+    print(f"configs[4] K=5 T=1000 B=32 config dims: fp16 vs fp32 HIP max |y0 delta| {d_y0:.2e}, max |class-prob delta| {d_pr:.2e}; "
+          f"fp32 HIP vs CPU oracle (member 0) |y0 delta| {d_cpu:.2e}, |prob delta| {p_cpu:.2e}")
+    assert d_cpu < 1e-4 and p_cpu < 1e-3                   # the reference's criterion, fp32, every row
+    assert d_pr < 5e-3 and d_y0 < 5e-3                      # fp16 operand mode against the fp32 arithmetic, every row
+    top = s32.topk(2, dim=2).values                         # vote = argmax of raw y_0: equal away from near-ties
+    safe = (top[..., 0] - top[..., 1]).amin(dim=0) > 10 * d_y0
+    assert torch.equal(outs["f16"]["vote"][safe], outs["f32"]["vote"][safe])

@@ -134,9 +134,10 @@ def test_classifier_fp16_vs_oracle_fp16_mode():
 
 def test_config5_pipeline_fp16_flag_end_to_end():
     """BASELINE config 5 end to end in shape (ISICSkinCancer temperature, K = 5, T = 1000) with the --fp16 switch of the runner:
-    ViT prefix (GEMMs + MFMA attention), mapping MLPs, encoder and sampler blocks on fp16 operands.  Checked against the oracle in its
-    fp16-operand mode (samples relative to the trajectory scale -- T = 1000 amplifies rounding by ~160) and against the
-    fp32 HIP path of the same runner inputs (the mode stays within 5e-2 in class probability on non-saturated rows)."""
+    ViT prefix (GEMMs + MFMA attention), mapping MLPs, encoder and sampler blocks on fp16 operands.  The members carry the
+    denoiser-structured init (contractive chains, pinned by golden s4), so every row is tame and every row is checked: against
+    the oracle in its fp16-operand mode and against the fp32 HIP path on the same inputs (class probabilities within 1e-3 --
+    the yhat from the fp16 conditioner is what moves them, the chain itself forgets fp16 rounding)."""
     import argparse
     from nested_diffusion_amd.mapping import Classifier, GuidingConditioner, VisionTransformer
     from nested_diffusion_amd.runner import Diffusion
@@ -146,7 +147,7 @@ def test_config5_pipeline_fp16_flag_end_to_end():
     vp = ref_cpu.init_vit_params(embed=embed, depth=depth, patch=patch, img=img, seed=13)
     n_tok = (img // patch) ** 2
     mlps = [ref_cpu.init_classifier_params(n_tok * embed, widths=(64, 32, 32), seed=120 + i) for i in range(K)]
-    members = [ref_cpu.init_cond_model_params(D, H, Fd, C, T, True, seed=140 + i) for i in range(K)]
+    members = [ref_cpu.init_cond_model_params(D, H, Fd, C, T, True, seed=140 + i, denoiser=True) for i in range(K)]
     cfg = ns(data=ns(dataset="ISICSkinCancer", num_classes=C), model=ns(data_dim=D, hidden_dim=H, feature_dim=Fd, arch="linear"),
              diffusion=ns(timesteps=T, beta_schedule="linear", beta_start=1e-4, beta_end=0.02, aux_cls=ns(arch="sevit"),
                           trained_aux_cls_ckpt_path="", trained_diffusion_ckpt_path=[[]], include_guidance=True),
@@ -170,12 +171,12 @@ def test_config5_pipeline_fp16_flag_end_to_end():
         alphas, omabs = ref_cpu.schedule_tables("linear", T, 1e-4, 0.02)
         raw, vote, prob = ref_cpu.ensemble_predict(members, x.flatten(1), yhat, T, alphas, omabs, noise, 0.3162, hoist=True)
     ref, got = torch.stack(raw), outs["f16"]["samples"].cpu()
-    scale = max(1.0, float(ref.abs().max()))
-    assert (got - ref).abs().max() < 2e-2 * scale, float((got - ref).abs().max() / scale)
-    tame = (ref.abs().amax(dim=(0, 2)) < 50)
-    if tame.any():
-        assert (outs["f16"]["prob"].cpu() - prob)[tame].abs().max() < 2e-2
-        assert (outs["f16"]["prob"] - outs["f32"]["prob"]).cpu()[tame].abs().max() < 5e-2
+    assert float(ref.abs().max()) < 8.0                                   # tame: every row counts
+    d_y0 = float((got - ref).abs().max())
+    d_pr = float((outs["f16"]["prob"].cpu() - prob).abs().max())
+    d_32 = float((outs["f16"]["prob"] - outs["f32"]["prob"]).abs().max())
+    print(f"fp16 T=1000: max |y0 - fp16 oracle| = {d_y0:.2e}, class-prob delta vs fp16 oracle {d_pr:.2e}, vs fp32 HIP {d_32:.2e}")
+    assert d_y0 < 2e-3 and d_pr < 1e-3 and d_32 < 5e-3
 
 
 @pytest.mark.parametrize("M,K,N,act,res", [(6272, 768, 768, None, True), (392, 768, 2304, None, False), (6250, 768, 3070, "gelu", True),

@@ -175,9 +175,8 @@ def test_config_dims_vs_reference_golden():
 
 def test_isic_config_t1000_vs_oracle():
     """BASELINE config 5 in shape (ISICSkinCancer: temperature 0.3162; K = 5 members; T = 1000 steps), fp32, small dims.
-    T = 1000 amplifies rounding by 1/sqrt(abar_t) (~160 at t = 999): samples are compared relative to the trajectory scale,
-    class probabilities with the 1e-3 criterion on the rows whose samples stay in the range where convert_to_prob is not
-    saturated-and-discontinuous (|y| < 50)."""
+    The members carry the denoiser-structured init (oracle/ref_cpu.py; pinned by golden s4): their chains are contractive
+    like a trained estimator's, every sample stays O(1), and the 1e-3 class-probability criterion is asserted on EVERY row."""
     from nested_diffusion_amd.mapping import Classifier, GuidingConditioner, VisionTransformer
     from nested_diffusion_amd.runner import Diffusion
     embed, heads, depth, img, patch, K, B, T, mc, C = 128, 2, 5, 32, 16, 5, 4, 1000, 1, 2
@@ -185,7 +184,7 @@ def test_isic_config_t1000_vs_oracle():
     vp = ref_cpu.init_vit_params(embed=embed, depth=depth, patch=patch, img=img, seed=13)
     n_tok = (img // patch) ** 2
     mlps = [ref_cpu.init_classifier_params(n_tok * embed, widths=(64, 32, 16), seed=120 + i) for i in range(K)]
-    members = [ref_cpu.init_cond_model_params(D, H, Fd, C, T, True, seed=140 + i) for i in range(K)]
+    members = [ref_cpu.init_cond_model_params(D, H, Fd, C, T, True, seed=140 + i, denoiser=True) for i in range(K)]
     cfg = small_config(D, H, Fd, C, T, B, dataset="ISICSkinCancer")
     cond = GuidingConditioner(VisionTransformer(vp, heads), [Classifier(m) for m in mlps])
     runner = Diffusion(ns(seed=1, mc_trials=mc), cfg, device="cuda", conditioner=cond, noise_estimator_states=members)
@@ -200,10 +199,10 @@ def test_isic_config_t1000_vs_oracle():
     alphas, omabs = ref_cpu.schedule_tables("linear", T, 1e-4, 0.02)
     raw, vote, prob = ref_cpu.ensemble_predict(members, x.flatten(1), yhat, T, alphas, omabs, noise, runner.temperature, hoist=True)
     ref, got = torch.stack(raw), out["samples"].cpu()
-    assert (got - ref).abs().max() < 5e-3 * max(1.0, float(ref.abs().max()))
-    tame = (ref.abs().amax(dim=(0, 2)) < 50)
-    if tame.any():
-        assert (out["prob"].cpu() - prob)[tame].abs().max() < 1e-3
+    assert float(ref.abs().max()) < 8.0                                   # tame: every row counts
+    assert (got - ref).abs().max() < 2e-4, float((got - ref).abs().max())
+    assert (out["prob"].cpu() - prob).abs().max() < 1e-3
+    assert torch.equal(out["vote"].cpu(), vote)
 
 
 def test_calibrate_ece_equals_oracle_on_cached_samples():
