@@ -316,22 +316,37 @@ def main():
         alg = K * (wb * F * F + 4.0 * 2 * F + wb * 2 * M * F)
         achieved = alg / (avg_us * 1e-6) / 1e9 if n_probe else None
         roof = {"bound": "hbm", "kernel": plan["name"], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "alg_bytes_per_launch": alg}
-        traffic = None
+                "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "alg_bytes_per_launch": alg,
+                "label": "HBM + Infinity Cache: algorithmic bytes DELIVERED to the CUs per second over the 8 TB/s HBM3E peak"}
+        # Part of the step weights is kept resident in the 256 MiB Infinity Cache across steps (default-policy loads, the rest is
+        # streamed from HBM with nontemporal loads), so `achieved` is not a DRAM rate.  `hbm_side` subtracts the resident bytes:
+        # the rate the DRAM itself has to sustain for this launch time.
+        keep2, keep3 = eng.resident_weight_bytes()
+        res = 0.5 * (keep2 + keep3)
+        roof["hbm_side"] = ({"achieved": (alg - res) / (avg_us * 1e-6) / 1e9, "frac": (alg - res) / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                             "unit": "GB/s", "resident_bytes_per_launch": res,
+                             "note": f"lin2 launches read {keep2 / 1e6:.0f} MB and lin3 launches {keep3 / 1e6:.0f} MB of weights out of the "
+                                     "Infinity Cache (a memory-side cache: those bytes still cross the same fabric links to the XCDs)"}
+                            if n_probe else None)
+        traffic, why = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath) and args.dtype == "f32" and M == 32 and K == 5:
+        if not (args.dtype == "f32" and M == 32 and K == 5):
+            why = (f"no PMC profile is committed for this shape (dtype {args.dtype}, M = {M} rows, K = {K} members): profiles/traffic.json "
+                   "holds the counters of the headline shape only (f32, M = 32, K = 5)")
+        elif not os.path.exists(tpath):
+            why = "profiles/traffic.json is missing"
+        else:
             try:
                 traffic = json.load(open(tpath)).get("k_skinny_bytes_per_launch")
-            except Exception:
-                traffic = None
+            except Exception as e:
+                why = f"profiles/traffic.json unreadable: {e}"
         roof["traffic"] = traffic
         # the same launches also issue K*2*M*F*F exact-f32 MFMA flop: at M = 32 rows that is 34 us of matrix-pipe time per launch,
         # so the kernel sits against BOTH the stream and the f32 matrix pipe (PMC SQ_VALU_MFMA_BUSY 0.55, profiles/r02_pmc_mfma.csv)
         roof["co_limit_mfma_frac"] = (K * 2.0 * M * F * F / (avg_us * 1e-6) / 1e12 / F32_MFMA_PEAK_TF) if (n_probe and args.dtype == "f32") else None
-        roof["note"] = ("bytes delivered to the CUs per second: ~208 MB of the 2*K*F*F*4 weight bytes a step reads are kept resident in the "
-                        "256 MiB Infinity Cache across steps (default-policy loads; the rest streams from HBM with nontemporal loads)")
         roof["traffic_source"] = ("profiles/traffic.json: rocprofv3 PMC (FETCH_SIZE x2 + WRITE_SIZE, separate passes) of this kernel at this "
-                                  "shape, REPLAYED from the committed profile, not measured by this run") if traffic else None
+                                  "shape, REPLAYED from the committed profile, not measured by this run; FETCH_SIZE counts Infinity-Cache "
+                                  "hits too") if traffic else f"null: {why}"
     else:
         # M = B*mc rows > 64: the blocks are compute-bound f32-MFMA GEMMs (2*M*F*F flop per member and launch)
         alg = K * 2.0 * M * F * F

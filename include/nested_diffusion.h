@@ -138,6 +138,10 @@ int nd_sample(nd_handle h, int member0, int n_members, const float *yhat_dev, co
  * [2] lin3+lin4 block, [3] an EMPTY interval (two record nodes back to back): what one record node adds to every
  * interval, to be subtracted when a kernel's own duration is wanted; *n_samples = probed steps.  out_us holds 4 floats. */
 int nd_set_profiling(nd_handle h, int enable);
+/* Weight bytes of one step launch (block 0: lin2 of all loaded members, 1: lin3) that are read with default-policy loads and so
+ * stay resident in the 256 MiB Infinity Cache from step to step; the rest is streamed from HBM with nontemporal loads.  Lets the
+ * roofline report separate bytes DELIVERED to the CUs from bytes that come out of DRAM.  -1 on a bad argument. */
+long long nd_resident_weight_bytes(nd_handle h, int block);
 int nd_profile_read(nd_handle h, float *out_us, int *n_samples);
 
 /* Copy of an internal per-member activation (tests / debugging), converted from the packed layout to

@@ -76,6 +76,7 @@ SIGNATURES = {
     "nd_sample": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "nd_set_profiling": (_i, [_vp, _i]),
     "nd_profile_read": (_i, [_vp, C.POINTER(C.c_float), C.POINTER(_i)]),
+    "nd_resident_weight_bytes": (C.c_longlong, [_vp, _i]),
     "nd_member_buffer": (_i, [_vp, _i, _i, _vp, _i, _vp]),
     "nd_packed_bytes": (_sz, [_i, _i, _i]),
     "nd_pack_rows": (_i, [_vp, _vp, _i, _i, _i, _vp]),

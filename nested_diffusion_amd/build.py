@@ -18,7 +18,7 @@ SOURCES = ["nd_sampler.hip", "nd_ops.hip", "nd_vit.hip", "nd_image.hip", "nd_con
 EXTRA_FLAGS = {"nd_cond_gemm.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "nd_attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
                "nd_gemm_f32.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 HEADERS = [os.path.join(CSRC, "nd_common.hpp"), os.path.join(CSRC, "nd_cond_gemm.hpp"), os.path.join(os.path.dirname(HERE), "include", "nested_diffusion.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-Werror=inline-asm"]
 
 
 def _hipcc() -> str:

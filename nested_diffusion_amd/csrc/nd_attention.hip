@@ -22,8 +22,14 @@
 // explicit: a counted s_waitcnt vmcnt by the issuing wave + a barrier before a slot is read; lgkmcnt(0) + a barrier before it
 // is refilled.
 // one LDS-DMA piece: 64 lanes x 16 B from (uniform base + per-lane byte offset) to LDS bytes [lds_byte_addr, +1024)
+// m0 (the DMA's LDS base) is a reserved register the compiler also uses itself, so it must not appear in a clobber list
+// ("may not be preserved across the asm statement"): the statement saves it into a compiler-allocated SGPR and restores it,
+// i.e. m0 is unchanged across the statement by construction.  The DMA samples m0 when it issues, so restoring right behind it
+// is the same sequence the compiler emits for back-to-back __builtin_amdgcn_global_load_lds with different bases.
 __device__ __forceinline__ void nd_lds_dma16(const float* sbase, unsigned voff_bytes, unsigned lds_byte_addr) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff_bytes), "s"(sbase), "s"(lds_byte_addr) : "memory", "m0");
+    unsigned saved_m0;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(saved_m0) : "v"(voff_bytes), "s"(sbase), "s"(lds_byte_addr) : "memory");
 }
 
 // exp(x) for x <= 0 (softmax arguments), ~1 ulp: exp2 of the product x*log2(e) carried in two pieces (t rounded + its exact

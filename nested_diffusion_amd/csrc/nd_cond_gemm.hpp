@@ -49,6 +49,10 @@ static inline CondGemmPlan nd_cond_gemm_plan(int K, int N, int M, int nm, int ha
     p.TN = (nfr + CG_F - 1) / CG_F;
     p.ntl = 2 * p.TN;
     p.tiles = nm * p.TM * p.TN;
+    if (!p.use_tile) {          // the weight-streaming kernel takes this shape: no tile rounds, no k-split tail, no workspace
+        p.n_full = p.tiles; p.rem = 0; p.split = 1; p.ws_bytes = 0;
+        return p;
+    }
     const int ncu = nd_num_cus();
     p.n_full = (p.tiles / ncu) * ncu;
     p.rem = p.tiles - p.n_full;

@@ -406,7 +406,9 @@ static void carve(nd_handle_s* h, char* base, size_t* total) {
         m.e0 = cv.take<float>(pB * H); m.e1 = cv.take<float>(pB * H); m.xe = cv.take<float>(pB * F);
         m.ybuf = cv.take<float>(2 * mM * C);
         m.h1 = cv.take<float>(pM * F); m.h2 = cv.take<float>(pM * F);
-        m.epart = cv.take<float>((size_t)h->NT * mM * C);
+        // eps partials per (row, class): F/16 from k_skinny, 2 per 128-column tile from k_cond_gemm (more than F/16 when F = 16)
+        const size_t ntl_max = nd_cond_gemm_wanted((int)mM, h->half) ? (size_t)nd_cond_gemm_plan((int)F, (int)F, (int)mM, 1, h->half).ntl : 0;
+        m.epart = cv.take<float>(((size_t)h->NT > ntl_max ? (size_t)h->NT : ntl_max) * mM * C);
         // split-K slabs: sized for the deepest split any (B <= max_batch, member count) launch can pick
         m.splitk = cv.take<float>(h->enc_splitk ? (size_t)(D / 16 / 64 + 1) * pB * H : 1);
     }
@@ -649,6 +651,15 @@ extern "C" int nd_member_buffer(nd_handle h, int k, int which, float* dst_dev, i
         hipLaunchKernelGGL(k_unpack_rows, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, dst_dev, rows, F);
     HIP_CHECK(hipGetLastError());
     return ND_OK;
+}
+
+extern "C" long long nd_resident_weight_bytes(nd_handle h, int block) {
+    if (!h || block < 0 || block > 1 || h->descs_host.empty()) return -1;
+    const int K = h->cfg.n_members, F = h->cfg.feature_dim;
+    long long n = 0;
+    for (int k = 0; k < K; ++k)
+        if (h->members[k].loaded && h->descs_host[(size_t)(block ? L_LIN3 : L_LIN2) * K + k].keep) n += (long long)F * F * (h->half ? 2 : 4);
+    return n;
 }
 
 extern "C" int nd_set_profiling(nd_handle h, int enable) {

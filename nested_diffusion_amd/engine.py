@@ -154,6 +154,13 @@ class EnsembleEngine:
         self.probe_overhead_us = float(us[3])
         return float(us[0]), float(us[1]), float(us[2]), int(n.value)
 
+    def resident_weight_bytes(self) -> Tuple[int, int]:
+        """(lin2, lin3) weight bytes per step launch that are kept Infinity-Cache resident across steps."""
+        a, b = self.lib.nd_resident_weight_bytes(self.h, 0), self.lib.nd_resident_weight_bytes(self.h, 1)
+        if a < 0 or b < 0:
+            raise _lib.NdError("nd_resident_weight_bytes: members not loaded")
+        return int(a), int(b)
+
     def step_plan(self, M: int, n_members: Optional[int] = None) -> Dict[str, object]:
         """Which kernel the lin2 / lin3 blocks of a step run at M = B*mc rows (host-side plan, no launch)."""
         out = (C.c_int * 8)()

@@ -88,10 +88,9 @@ def dict2namespace(config):
     return namespace
 
 
-def parse_config(args):
-    """main.py:166-285 for the --test path: YAML -> Namespace, CLI overrides, log dirs, logger, seeds, device."""
-    import torch
-    args.log_path = os.path.join(args.exp, "logs", args.doc)
+def load_config(args):
+    """main.py:169-194: YAML -> nested Namespace plus the CLI overrides (--dataroot, --noise_prior, --no_cat_f_phi,
+    --timesteps, --num_sample).  Host-only: touches neither the file system beyond the YAML nor the GPU."""
     with open(args.config, "r") as f:
         if args.sample:
             raise NotImplementedError("--sample: NotImplementedError in the reference as well (main.py:246)")
@@ -100,12 +99,21 @@ def parse_config(args):
         new_config.data.dataroot = args.dataroot
     new_config.diffusion.noise_prior = True if args.noise_prior else False
     new_config.model.cat_y_pred = False if args.no_cat_f_phi else True
-    rank = int(os.environ.get("RANK", "0"))
     if not args.resume_training:
         if args.timesteps is not None:
             new_config.diffusion.timesteps = args.timesteps            # main.py:192-193
         if args.num_sample > 1:
             new_config.diffusion.num_sample = args.num_sample
+    return new_config
+
+
+def parse_config(args):
+    """main.py:166-285 for the --test path: YAML -> Namespace, CLI overrides, log dirs, logger, seeds, device."""
+    import torch
+    args.log_path = os.path.join(args.exp, "logs", args.doc)
+    new_config = load_config(args)
+    rank = int(os.environ.get("RANK", "0"))
+    if not args.resume_training:
         if rank == 0:
             if os.path.exists(args.log_path):
                 if not args.ni:
@@ -164,9 +172,11 @@ def main(argv=None) -> int:
         raise
     logging.info("Writing log file to {}".format(args.log_path))
     logging.info("Exp instance id = {}".format(os.getpid()))
+    if args.loss != 'card_onehot_conditional':
+        # main.py:305-311: raised BEFORE the reference's try block, so the process dies with a traceback and a non-zero exit code
+        nd_dist.shutdown()
+        raise NotImplementedError("Invalid loss option")
     try:
-        if args.loss != 'card_onehot_conditional':
-            raise NotImplementedError("Invalid loss option")      # main.py:310-311
         from .runner import Diffusion
         runner = Diffusion(args, config, device=config.device)
         start_time = time.time()
