@@ -122,7 +122,8 @@ int nd_p_sample(nd_handle h, int member, const float *y_dev, const float *yhat_d
  *   yhat_dev  [n_members, B, C]   eps_theta condition (y_0_hat)
  *   ymean_dev [n_members, B, C]   prior mean y_T_mean (same tensor in the reference, quirk Q2)
  *   noise_dev [n_members, T, M, C] the reference's RNG draws in draw order: index 0 = initial
- *              randn_like (:139), index i>=1 = the draw of p_sample at t = T-i (:67)
+ *              randn_like (:139), index i>=1 = the draw of p_sample at t = T-i (:67); NULL = draw them in the library
+ *              (Philox, see nd_seed): throughput mode
  *   y0_out_dev [n_members, M, C]
  *   seq_out_dev optional [n_members, T+1, M, C]: y_T, y_{T-1}, ..., y_0 (only_last_sample=False)
  * The 3T+1 kernels are replayed from one hipGraph per (member range, B, mc, T, pointers) when
@@ -213,6 +214,89 @@ int nd_softmax_rows(const float *x_dev, float *out_dev, int rows, int C, void *s
  *   probs_out optional [S, B, C]: per-sample probabilities (what the reference leaves in mc_samples, quirk Q4) */
 int nd_aggregate(const float *samples_dev, float *prob_out_dev, int64_t *vote_out_dev, float *probs_out_dev,
                  int S, int B, int C, float temperature, void *stream);
+
+/* ---- in-library noise (throughput mode) ------------------------------------------------------------------
+ * The reference draws its Gaussian noise inside the loop with the global torch generator (diffusion_utils.py:67, 139:
+ * randn_like); CPU torch.randn cannot be reproduced on a device, so parity runs pass the draws in (noise_dev).  With
+ * noise_dev == NULL, nd_sample / nd_predict_batch draw them here: Philox4x32-10 (Salmon et al., SC'11), key = the 64-bit
+ * seed, counter = (global image index, trial | member << 16 | class-quad << 24, draw index i (0 = y_T, i = the draw of
+ * p_sample at t = T-i), batch counter); the four 32-bit outputs give four normals by Box-Muller (classes 4q..4q+3).
+ * The draws of image g do not depend on how a batch is sharded over ranks (first_image = the global index of this rank's
+ * first image), and the batch counter -- kept on the device, advanced by the sampler itself -- makes successive batches
+ * differ.  nd_seed resets it to 0.  Synchronises the device (rare: once per run). */
+int nd_seed(nd_handle h, uint64_t seed, uint32_t first_image);
+/* The same generator as a standalone operator (tests, known-answer checks): out_dev [n_members, T, mc*B, C], row = trial*B + b. */
+int nd_philox_normal(float *out_dev, int n_members, int T, int B, int mc, int C, uint64_t seed, uint32_t batch_counter,
+                     uint32_t first_image, void *stream);
+/* Raw Philox4x32-10 blocks (known-answer test): out_dev[4*i..4*i+3] = philox(counter = ctr_dev[4*i..], key). */
+int nd_philox_raw(const uint32_t *ctr_dev, uint32_t *out_dev, int n, uint32_t key0, uint32_t key1, void *stream);
+
+/* ---- conditioner: the mapping network (classification_train_separately.py:249-275, 330-348) -------------------
+ * cond_pred_model = {'vit': timm 0.4.12 vit_base_patch16_224, 'mlps': [mapping/models/mlp.py::Classifier] * K}.
+ * The handle holds POINTERS to the caller's device tensors (the caller keeps them alive, as a torch module does) and one
+ * caller-provided workspace for the activations. */
+typedef struct nd_cond_s *nd_cond;
+typedef struct {
+    int32_t img_size, patch, in_chans;   /* 224, 16, 3 */
+    int32_t embed_dim, num_heads;        /* 768, 12 (head dim must be 64) */
+    int32_t mlp_hidden;                  /* 3072 (timm Mlp hidden = 4 * embed) */
+    int32_t n_blocks;                    /* ViT blocks available to nd_vit_block (>= n_mlps) */
+    int32_t n_mlps;                      /* K mapping MLPs: MLP i reads the tokens after blocks[0..i] (:336-345) */
+    int32_t mlp_widths[3];               /* 4096, 2048, 128 (mapping/models/mlp.py:12-18) */
+    int32_t num_classes;                 /* C */
+    int32_t max_batch;
+    int32_t max_tokens;                  /* tokens per image nd_vit_block may be called with (196 on the mapping path, 197 with
+                                          * the cls token of the full forward) */
+    int32_t operand_dtype;               /* ND_DTYPE_F32 | ND_DTYPE_F16 (Linear weights fp16 row-major, MLP weights frag32h) */
+    float ln_eps;                        /* 1e-6: timm's norm_layer = partial(nn.LayerNorm, eps=1e-6) */
+} nd_cond_config;
+/* timm PatchEmbed.proj viewed [embed, in_chans*patch*patch] (+ bias); fp32, or fp16 in the fp16 mode. */
+typedef struct { const void *proj_w; const float *proj_b; } nd_patch_embed_weights;
+/* One timm Block: norm1, attn.qkv [3E,E], attn.proj [E,E], norm2, mlp.fc1 [4E,E], mlp.fc2 [E,4E]; Linear weights row-major
+ * [out,in] (nn.Linear layout), fp32 or fp16 per operand_dtype; everything else fp32. */
+typedef struct {
+    const float *norm1_w, *norm1_b;
+    const void *qkv_w;  const float *qkv_b;
+    const void *proj_w; const float *proj_b;
+    const float *norm2_w, *norm2_b;
+    const void *fc1_w;  const float *fc1_b;
+    const void *fc2_w;  const float *fc2_b;
+} nd_vit_block_weights;
+/* One mapping MLP: linear1..4 weights as nd_pack_rows images (same dtype as the config) + fp32 biases. */
+typedef struct { const void *w_packed[4]; const float *bias[4]; } nd_mlp_weights;
+
+size_t nd_cond_workspace_bytes(const nd_cond_config *cfg);
+int nd_cond_create(const nd_cond_config *cfg, nd_cond *out);
+int nd_cond_destroy(nd_cond c);
+const nd_cond_config *nd_cond_get_config(nd_cond c);
+int nd_cond_bind_workspace(nd_cond c, void *workspace_dev, size_t bytes);
+int nd_cond_set_patch_embed(nd_cond c, const nd_patch_embed_weights *w);
+int nd_cond_set_block(nd_cond c, int block, const nd_vit_block_weights *w);
+int nd_cond_set_mlp(nd_cond c, int i, const nd_mlp_weights *w);
+
+/* timm 0.4.12 Block.forward on tokens [B, N, embed] (pre-LN: x += attn(norm1(x)); x += mlp(norm2(x)); exact-erf GELU):
+ * the calls `vit.blocks[j](tmp)` at classification_train_separately.py:339-340.  tok_out_dev may alias tok_in_dev. */
+int nd_vit_block(nd_cond c, int block, const float *tok_in_dev, float *tok_out_dev, int B, int N, void *stream);
+
+/* Diffusion.compute_guiding_prediction (:330-345) for the K mapping members: patch_embed (no cls token, no pos_embed; pos_drop
+ * is the identity in eval), blocks[0..i] with the prefix SHARED between members (15 -> K block evaluations; eval-mode blocks
+ * are deterministic, same values), mlps[i] right after block i.  images_dev [B, in_chans, img, img] ->
+ * logits_out_dev [K, B, C]; yhat_out_dev (optional) [K, B, C] = softmax(logits, dim=1) (:755-758).
+ * The never-sampled (K+1)-th element, vit(x) (:346, quirk Q1), is not computed here.  No allocation, no synchronisation:
+ * capturable into a hipGraph. */
+int nd_guiding_prediction(nd_cond c, const float *images_dev, float *logits_out_dev, float *yhat_out_dev, int B, void *stream);
+
+/* ---- the whole hot path of one test batch as ONE launch (classification_train_separately.py:749-794) ----------
+ * guiding prediction -> softmax -> encoder hoist of every member -> K x mc p_sample_loops -> convert_to_prob / mean / vote,
+ * replayed from one hipGraph per (pointers, B, mc, T) when use_graph != 0.  Device pointers, caller-owned:
+ *   images_dev [B, in_chans, img, img] (flattened [B, D] for the noise estimators, :747)
+ *   noise_dev  [K, T, mc*B, C] in the reference's draw order, or NULL for in-library Philox noise (nd_seed)
+ *   out->samples [K*mc, B, C] raw y_0, member-major then trial (the order of mc_samples, :767-784)
+ *   out->prob [B, C], out->vote [B] int64, out->probs [K*mc, B, C] (optional), out->yhat [K, B, C]
+ * The ensemble handle must hold exactly cfg.n_mlps loaded members (member k is conditioned on mapping MLP k). */
+typedef struct { float *samples; float *prob; int64_t *vote; float *probs; float *yhat; } nd_batch_out;
+int nd_predict_batch(nd_handle h, nd_cond c, const float *images_dev, const float *noise_dev, const nd_batch_out *out,
+                     int B, int mc, int T, float temperature, int use_graph, void *stream);
 
 /* ---- reporting tail of test_atk (classification_train_separately.py:801-838) --------------------- */
 /* Per-image spread of the S = K*mc per-sample probabilities (what the reference keeps in pred_mc, quirk Q4):

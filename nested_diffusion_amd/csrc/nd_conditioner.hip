@@ -1,0 +1,235 @@
+// nd_conditioner.hip -- the mapping network as ONE C-level call (gfx950 only): host-side sequencing of the ViT and
+// mapping-MLP kernels of nd_vit.hip / nd_gemm_f32.hip / nd_attention.hip / nd_ops.hip.
+//
+// Reference (file:line relative to the reference checkout):
+//   diffusion/classification_train_separately.py:249-275   cond_pred_model = {'vit', 'mlps'} (whole-module pickles)
+//   diffusion/classification_train_separately.py:330-348   compute_guiding_prediction
+//   mapping/models/mlp.py:23-29                             Classifier.forward
+//   timm 0.4.12 vision_transformer.py (third-party, absent: restated from its published semantics)  Block.forward
+//
+// Nothing here allocates or synchronises, so a call can be captured into a hipGraph (nd_predict_batch does).
+#include <hip/hip_runtime.h>
+#include <vector>
+#include <cstring>
+#include "../../include/nested_diffusion.h"
+
+int nd_set_err(int code, const char* fmt, ...);
+
+struct nd_cond_s {
+    nd_cond_config cfg{};
+    nd_patch_embed_weights pe{};
+    std::vector<nd_vit_block_weights> blocks;
+    std::vector<nd_mlp_weights> mlps;
+    std::vector<char> have_block, have_mlp;
+    bool have_pe = false;
+    char* ws = nullptr;
+    size_t ws_bytes = 0;
+    // carved activations
+    float *cols = nullptr, *tok = nullptr, *mid_tok = nullptr, *h = nullptr, *qkv = nullptr, *att = nullptr, *fc1 = nullptr;
+    float* m[3] = {nullptr, nullptr, nullptr};
+    void *gemm_ws = nullptr, *lin_ws = nullptr;
+    size_t gemm_ws_bytes = 0, lin_ws_bytes = 0;
+};
+
+static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+static int check_cfg(const nd_cond_config* c) {
+    if (!c) return nd_set_err(ND_ERR_ARG, "cfg is NULL");
+    if (c->patch < 4 || (c->patch % 4) || c->img_size < c->patch || (c->img_size % c->patch) || c->in_chans < 1)
+        return nd_set_err(ND_ERR_ARG, "patch must be a multiple of 4 dividing img_size");
+    if (c->num_heads < 1 || c->embed_dim != 64 * c->num_heads) return nd_set_err(ND_ERR_ARG, "embed_dim must be 64 * num_heads");
+    if (c->operand_dtype != ND_DTYPE_F32 && c->operand_dtype != ND_DTYPE_F16) return nd_set_err(ND_ERR_ARG, "unknown operand_dtype");
+    const int km = c->operand_dtype == ND_DTYPE_F16 ? 32 : 16;
+    const int kpe = c->in_chans * c->patch * c->patch;
+    if ((c->embed_dim % km) || (c->mlp_hidden % km) || c->mlp_hidden < km || (kpe % km))
+        return nd_set_err(ND_ERR_ARG, "embed_dim, mlp_hidden and in_chans*patch^2 must be multiples of %d", km);
+    if (c->n_mlps < 1 || c->n_blocks < c->n_mlps) return nd_set_err(ND_ERR_ARG, "need 1 <= n_mlps <= n_blocks");
+    for (int i = 0; i < 3; ++i)
+        if (c->mlp_widths[i] < km || (c->mlp_widths[i] % km)) return nd_set_err(ND_ERR_ARG, "mlp_widths must be multiples of %d", km);
+    if (c->num_classes < 1 || c->max_batch < 1) return nd_set_err(ND_ERR_ARG, "num_classes / max_batch invalid");
+    const int ntok = (c->img_size / c->patch) * (c->img_size / c->patch);
+    if (c->max_tokens < ntok || c->max_tokens > 256) return nd_set_err(ND_ERR_ARG, "max_tokens must be in [%d, 256]", ntok);
+    if (!(c->ln_eps > 0.f)) return nd_set_err(ND_ERR_ARG, "ln_eps must be > 0");
+    return ND_OK;
+}
+
+static inline size_t zmax(size_t a, size_t b) { return a > b ? a : b; }
+
+// carve with base == nullptr computes the size only
+static void carve(nd_cond_s* c, char* base, size_t* total) {
+    const nd_cond_config& g = c->cfg;
+    const size_t B = g.max_batch, N = g.max_tokens, E = g.embed_dim, Hd = g.mlp_hidden;
+    const size_t ntok = (size_t)(g.img_size / g.patch) * (g.img_size / g.patch), kpe = (size_t)g.in_chans * g.patch * g.patch;
+    const size_t R = B * N;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off = al256(off + bytes); return p; };
+    c->cols = (float*)take(B * ntok * kpe * 4);
+    c->tok = (float*)take(R * E * 4);
+    c->mid_tok = (float*)take(R * E * 4);
+    c->h = (float*)take(R * E * 4);
+    c->qkv = (float*)take(R * 3 * E * 4);
+    c->att = (float*)take(R * E * 4);
+    c->fc1 = (float*)take(R * Hd * 4);
+    for (int i = 0; i < 3; ++i) c->m[i] = (float*)take(B * (size_t)g.mlp_widths[i] * 4);
+    const int dt = g.operand_dtype;
+    size_t gw = 0;
+    const int rows[2] = {(int)(B * ntok), (int)R};
+    for (int r : rows) {
+        gw = zmax(gw, nd_gemm_workspace_bytes(r, (int)kpe, (int)E, dt));
+        gw = zmax(gw, nd_gemm_workspace_bytes(r, (int)E, (int)(3 * E), dt));
+        gw = zmax(gw, nd_gemm_workspace_bytes(r, (int)E, (int)E, dt));
+        gw = zmax(gw, nd_gemm_workspace_bytes(r, (int)E, (int)Hd, dt));
+        gw = zmax(gw, nd_gemm_workspace_bytes(r, (int)Hd, (int)E, dt));
+    }
+    c->gemm_ws_bytes = gw;
+    c->gemm_ws = take(gw + 16);
+    const int dims[5] = {(int)(ntok * E), g.mlp_widths[0], g.mlp_widths[1], g.mlp_widths[2], g.num_classes};
+    size_t lw = 0;
+    for (int l = 0; l < 4; ++l)
+        for (int b = 1; b <= (int)B; ++b) lw = zmax(lw, nd_linear_workspace_bytes(b, dims[l], dims[l + 1], dt));   // plans differ with the row count
+    c->lin_ws_bytes = lw;
+    c->lin_ws = take(lw);
+    *total = off;
+}
+
+extern "C" size_t nd_cond_workspace_bytes(const nd_cond_config* cfg) {
+    if (check_cfg(cfg) != ND_OK) return 0;
+    nd_cond_s tmp;
+    tmp.cfg = *cfg;
+    size_t total = 0;
+    carve(&tmp, nullptr, &total);
+    return total;
+}
+
+extern "C" int nd_cond_create(const nd_cond_config* cfg, nd_cond* out) {
+    if (!out) return nd_set_err(ND_ERR_ARG, "out is NULL");
+    int rc = check_cfg(cfg);
+    if (rc != ND_OK) return rc;
+    nd_cond_s* c = new nd_cond_s();
+    c->cfg = *cfg;
+    c->blocks.resize(cfg->n_blocks);
+    c->mlps.resize(cfg->n_mlps);
+    c->have_block.assign(cfg->n_blocks, 0);
+    c->have_mlp.assign(cfg->n_mlps, 0);
+    *out = c;
+    return ND_OK;
+}
+
+extern "C" const nd_cond_config* nd_cond_get_config(nd_cond c) { return c ? &c->cfg : nullptr; }
+
+extern "C" int nd_cond_destroy(nd_cond c) {
+    delete c;
+    return ND_OK;
+}
+
+extern "C" int nd_cond_bind_workspace(nd_cond c, void* ws, size_t bytes) {
+    if (!c || !ws) return nd_set_err(ND_ERR_ARG, "conditioner / workspace is NULL");
+    if ((uintptr_t)ws & 255) return nd_set_err(ND_ERR_ARG, "workspace must be 256-byte aligned");
+    size_t need = 0;
+    carve(c, (char*)ws, &need);
+    if (bytes < need) return nd_set_err(ND_ERR_ARG, "workspace too small: %zu < %zu", bytes, need);
+    c->ws = (char*)ws;
+    c->ws_bytes = bytes;
+    return ND_OK;
+}
+
+template <typename T>
+static int all_set(const T* w, const char* what) {
+    const void* const* pp = reinterpret_cast<const void* const*>(w);
+    for (size_t i = 0; i < sizeof(T) / sizeof(void*); ++i)
+        if (!pp[i]) return nd_set_err(ND_ERR_ARG, "%s pointer #%zu is NULL", what, i);
+    return ND_OK;
+}
+
+extern "C" int nd_cond_set_patch_embed(nd_cond c, const nd_patch_embed_weights* w) {
+    if (!c || !w) return nd_set_err(ND_ERR_ARG, "NULL argument");
+    int rc = all_set(w, "nd_patch_embed_weights");
+    if (rc != ND_OK) return rc;
+    c->pe = *w;
+    c->have_pe = true;
+    return ND_OK;
+}
+
+extern "C" int nd_cond_set_block(nd_cond c, int block, const nd_vit_block_weights* w) {
+    if (!c || !w) return nd_set_err(ND_ERR_ARG, "NULL argument");
+    if (block < 0 || block >= c->cfg.n_blocks) return nd_set_err(ND_ERR_ARG, "block %d outside [0,%d)", block, c->cfg.n_blocks);
+    int rc = all_set(w, "nd_vit_block_weights");
+    if (rc != ND_OK) return rc;
+    c->blocks[block] = *w;
+    c->have_block[block] = 1;
+    return ND_OK;
+}
+
+extern "C" int nd_cond_set_mlp(nd_cond c, int i, const nd_mlp_weights* w) {
+    if (!c || !w) return nd_set_err(ND_ERR_ARG, "NULL argument");
+    if (i < 0 || i >= c->cfg.n_mlps) return nd_set_err(ND_ERR_ARG, "mlp %d outside [0,%d)", i, c->cfg.n_mlps);
+    int rc = all_set(w, "nd_mlp_weights");
+    if (rc != ND_OK) return rc;
+    c->mlps[i] = *w;
+    c->have_mlp[i] = 1;
+    return ND_OK;
+}
+
+#define ND_TRY(call)          \
+    do {                      \
+        int _rc = (call);     \
+        if (_rc != ND_OK) return _rc; \
+    } while (0)
+
+static int vit_block(nd_cond_s* c, int block, const float* tin, float* tout, int B, int N, void* st) {
+    const nd_cond_config& g = c->cfg;
+    const nd_vit_block_weights& w = c->blocks[block];
+    const int E = g.embed_dim, Hd = g.mlp_hidden, R = B * N, dt = g.operand_dtype;
+    // x = x + attn(norm1(x))
+    ND_TRY(nd_layernorm(tin, w.norm1_w, w.norm1_b, c->h, R, E, g.ln_eps, st));
+    ND_TRY(nd_gemm_bias_act(c->h, w.qkv_w, w.qkv_b, nullptr, c->qkv, R, E, 3 * E, ND_ACT_NONE, dt, c->gemm_ws, c->gemm_ws_bytes, st));
+    ND_TRY(nd_attention(c->qkv, c->att, B, N, g.num_heads, 64, dt, st));
+    ND_TRY(nd_gemm_bias_act(c->att, w.proj_w, w.proj_b, tin, c->mid_tok, R, E, E, ND_ACT_NONE, dt, c->gemm_ws, c->gemm_ws_bytes, st));
+    // x = x + mlp(norm2(x)), exact-erf GELU
+    ND_TRY(nd_layernorm(c->mid_tok, w.norm2_w, w.norm2_b, c->h, R, E, g.ln_eps, st));
+    ND_TRY(nd_gemm_bias_act(c->h, w.fc1_w, w.fc1_b, nullptr, c->fc1, R, E, Hd, ND_ACT_GELU, dt, c->gemm_ws, c->gemm_ws_bytes, st));
+    ND_TRY(nd_gemm_bias_act(c->fc1, w.fc2_w, w.fc2_b, c->mid_tok, tout, R, Hd, E, ND_ACT_NONE, dt, c->gemm_ws, c->gemm_ws_bytes, st));
+    return ND_OK;
+}
+
+extern "C" int nd_vit_block(nd_cond c, int block, const float* tok_in, float* tok_out, int B, int N, void* stream) {
+    if (!c || !c->ws) return nd_set_err(ND_ERR_STATE, "conditioner workspace not bound");
+    if (!tok_in || !tok_out) return nd_set_err(ND_ERR_ARG, "NULL tensor");
+    if (block < 0 || block >= c->cfg.n_blocks || !c->have_block[block]) return nd_set_err(ND_ERR_STATE, "block %d not set", block);
+    if (B < 1 || B > c->cfg.max_batch || N < 1 || N > c->cfg.max_tokens)
+        return nd_set_err(ND_ERR_ARG, "B=%d / N=%d outside [1,%d] / [1,%d]", B, N, c->cfg.max_batch, c->cfg.max_tokens);
+    return vit_block(c, block, tok_in, tok_out, B, N, stream);
+}
+
+extern "C" int nd_guiding_prediction(nd_cond c, const float* images, float* logits_out, float* yhat_out, int B, void* stream) {
+    if (!c || !c->ws) return nd_set_err(ND_ERR_STATE, "conditioner workspace not bound");
+    if (!images || !logits_out) return nd_set_err(ND_ERR_ARG, "NULL tensor");
+    const nd_cond_config& g = c->cfg;
+    if (B < 1 || B > g.max_batch) return nd_set_err(ND_ERR_ARG, "B=%d outside [1,%d]", B, g.max_batch);
+    if (!c->have_pe) return nd_set_err(ND_ERR_STATE, "patch embedding not set");
+    for (int i = 0; i < g.n_mlps; ++i)
+        if (!c->have_block[i] || !c->have_mlp[i]) return nd_set_err(ND_ERR_STATE, "block / mlp %d not set", i);
+    const int E = g.embed_dim, gs = g.img_size / g.patch, ntok = gs * gs, kpe = g.in_chans * g.patch * g.patch, dt = g.operand_dtype;
+    const int C = g.num_classes;
+    // tmp = vit.patch_embed(x); vit.pos_drop is the identity in eval; no cls token, no pos_embed (:337-338, quirk Q3)
+    ND_TRY(nd_patchify(images, c->cols, B, g.in_chans, g.img_size, g.img_size, g.patch, stream));
+    ND_TRY(nd_gemm_bias_act(c->cols, c->pe.proj_w, c->pe.proj_b, nullptr, c->tok, B * ntok, kpe, E, ND_ACT_NONE, dt, c->gemm_ws,
+                            c->gemm_ws_bytes, stream));
+    const int dims[5] = {ntok * E, g.mlp_widths[0], g.mlp_widths[1], g.mlp_widths[2], C};
+    for (int i = 0; i < g.n_mlps; ++i) {
+        // member i's prefix blocks[0..i] reuse member i-1's tokens (:339-340 recomputes them from patch_embed: same values)
+        ND_TRY(vit_block(c, i, c->tok, c->tok, B, ntok, stream));
+        // mlps[i](tmp): reshape(-1, 196*768) -> 3 x (Linear, ReLU) -> Linear (mapping/models/mlp.py:23-29)
+        const nd_mlp_weights& w = c->mlps[i];
+        const float* x = c->tok;
+        float* logits = logits_out + (size_t)i * B * C;
+        for (int l = 0; l < 4; ++l) {
+            float* y = l < 3 ? c->m[l] : logits;
+            ND_TRY(nd_linear(x, w.w_packed[l], nullptr, w.bias[l], y, B, dims[l], dims[l + 1], l < 3 ? ND_ACT_RELU : ND_ACT_NONE, dt, c->lin_ws,
+                             c->lin_ws_bytes, stream));
+            x = y;
+        }
+        if (yhat_out) ND_TRY(nd_softmax_rows(logits, yhat_out + (size_t)i * B * C, B, C, stream));     // :755-758
+    }
+    return ND_OK;
+}

@@ -7,6 +7,7 @@
 //   diffusion/latent_model.py:93-105,169-184  ConditionalLinear / ConditionalModel.forward
 #include "nd_common.hpp"
 #include "nd_cond_gemm.hpp"
+#include "nd_rng.hpp"
 #include "../../include/nested_diffusion.h"
 
 #include <map>
@@ -28,7 +29,7 @@ extern "C" int nd_debug_set_wg_times(void* dev_ptr) {
     return hipMemcpyToSymbol(HIP_SYMBOL(nd_dbg_times), &dev_ptr, sizeof dev_ptr) == hipSuccess ? 0 : -1;
 }
 #endif
-extern "C" const char* nd_version(void) { return "libnd_hip gfx950 f32-mfma r2"; }
+extern "C" const char* nd_version(void) { return "libnd_hip gfx950 f32-mfma r3"; }
 int nd_set_err(int code, const char* fmt, ...) {
     char buf[512];
     va_list ap;
@@ -339,6 +340,17 @@ struct GraphKey {
     }
 };
 
+struct BatchKey {
+    const void *cond, *images, *noise, *samples, *prob, *vote, *probs, *yhat;
+    int B, mc, T;
+    unsigned temp_bits;
+    bool profiling;
+    bool operator<(const BatchKey& o) const {
+        return std::tie(cond, images, noise, samples, prob, vote, probs, yhat, B, mc, T, temp_bits, profiling) <
+               std::tie(o.cond, o.images, o.noise, o.samples, o.prob, o.vote, o.probs, o.yhat, o.B, o.mc, o.T, o.temp_bits, o.profiling);
+    }
+};
+
 struct nd_handle_s {
     nd_config cfg{};
     char* ws = nullptr;
@@ -353,11 +365,16 @@ struct nd_handle_s {
     float *alphas = nullptr, *omabs = nullptr;
     float* xpack = nullptr;                // frag16 [maxB][D] image batch shared by all members
     float* tile_ws = nullptr;              // k-slab accumulators of k_cond_gemm's split tail (large-M steps only)
+    unsigned long long* rng_state = nullptr;   // {seed, batch counter | first image << 32} of the in-library noise (nd_seed)
+    float* noise_ws = nullptr;             // [K][T][max_rows][C] draws of the in-library noise (noise_dev == NULL)
+    float* logits_ws = nullptr;            // [K][max_batch][C] guiding-prediction logits of nd_predict_batch
     int sched_T = 0;
     int NT = 0, S0 = 0;
     bool enc_splitk = false;
     int half = 0;                          // cfg.operand_dtype == ND_DTYPE_F16
     std::map<GraphKey, hipGraphExec_t> graphs;
+    std::map<BatchKey, hipGraphExec_t> batch_graphs;   // nd_predict_batch: the whole hot path of a batch
+    hipStream_t capture_stream = nullptr;              // only ever used to RECORD batch graphs, never to run anything
     int encoded_B = -1;
     bool profiling = false;
     std::vector<hipEvent_t> probe_events;   // 5 per probed step: e0 | head | e1 | lin2 | e2 | lin3 | e3 | (nothing) | e4
@@ -392,6 +409,9 @@ static void carve(nd_handle_s* h, char* base, size_t* total) {
     h->spke_dev = cv.take<SplitKEpiDesc>(K);
     h->alphas = cv.take<float>(T);
     h->omabs = cv.take<float>(T);
+    h->rng_state = cv.take<unsigned long long>(2);
+    h->noise_ws = cv.take<float>(K * T * mM * C);
+    h->logits_ws = cv.take<float>(K * mB * C);
     h->xpack = cv.take<float>(pB * D);
     h->tile_ws = cv.take<float>(nd_cond_gemm_wanted((int)mM, h->half) ? (size_t)CG_MAX_SLABS * CG_T * CG_T : 1);
     for (size_t k = 0; k < K; ++k) {
@@ -455,12 +475,15 @@ extern "C" int nd_create(const nd_config* cfg, nd_handle* out) {
 static void drop_graphs(nd_handle_s* h) {
     for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
     h->graphs.clear();
+    for (auto& kv : h->batch_graphs) (void)hipGraphExecDestroy(kv.second);
+    h->batch_graphs.clear();
 }
 
 extern "C" int nd_destroy(nd_handle h) {
     if (!h) return ND_OK;
     drop_graphs(h);
     for (hipEvent_t e : h->probe_events) (void)hipEventDestroy(e);
+    if (h->capture_stream) (void)hipStreamDestroy(h->capture_stream);
     delete h;
     return ND_OK;
 }
@@ -478,6 +501,15 @@ extern "C" int nd_bind_workspace(nd_handle h, void* ws, size_t bytes) {
     // activations: padded tile rows must hold finite values before the first kernel reads them
     HIP_CHECK(hipMemset(h->xpack, 0, (size_t)((char*)h->members[0].sc0 - (char*)h->xpack)));
     for (auto& m : h->members) HIP_CHECK(hipMemset(m.e0, 0, (size_t)((char*)m.splitk - (char*)m.e0)));
+    HIP_CHECK(hipMemset(h->rng_state, 0, 2 * sizeof(unsigned long long)));
+    return ND_OK;
+}
+
+extern "C" int nd_seed(nd_handle h, uint64_t seed, uint32_t first_image) {
+    if (!h || !h->ws) return nd_set_err(ND_ERR_STATE, "workspace not bound");
+    const unsigned long long st[2] = {(unsigned long long)seed, (unsigned long long)first_image << 32};   // batch counter 0
+    HIP_CHECK(hipDeviceSynchronize());          // no sampling graph may be reading the state while it is replaced
+    HIP_CHECK(hipMemcpy(h->rng_state, st, sizeof st, hipMemcpyHostToDevice));
     return ND_OK;
 }
 
@@ -843,34 +875,58 @@ static hipError_t emit_loop(nd_handle_s* h, Emitter& em, int m0, int nm, StepIO 
     return em.err;
 }
 
+// Enqueue (eager, or under stream capture) the kernels of one sampling call: [Philox fill] -> 3T+1 step kernels -> [advance].
+static int run_loop_eager(nd_handle_s* h, hipStream_t st, int m0, int nm, StepIO io, bool draw, int B, int mc, int T) {
+    if (draw) HIP_CHECK(nd_launch_philox_normal(h->noise_ws, h->rng_state, 0, 0, 0, nm, T, B, mc, h->cfg.y_dim, st));
+    Emitter em{st};
+    hipError_t e = emit_loop(h, em, m0, nm, io, B, mc, T);
+    if (e != hipSuccess) return nd_set_err(ND_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+    if (draw) HIP_CHECK(nd_launch_rng_advance(h->rng_state, st));
+    return ND_OK;
+}
+
 extern "C" int nd_sample(nd_handle h, int m0, int nm, const float* yhat_dev, const float* ymean_dev, const float* noise_dev,
                          float* y0_out_dev, float* seq_out_dev, int B, int mc, int T, int use_graph, void* stream) {
     int rc = check_range(h, m0, nm);
     if (rc != ND_OK) return rc;
-    if (!yhat_dev || !ymean_dev || !noise_dev || !y0_out_dev) return nd_set_err(ND_ERR_ARG, "NULL tensor");
+    if (!yhat_dev || !ymean_dev || !y0_out_dev) return nd_set_err(ND_ERR_ARG, "NULL tensor");
     rc = check_rows(h, B, mc, T);
     if (rc != ND_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
     const int C = h->cfg.y_dim, M = B * mc;
+    // noise_dev == NULL: the draws come from the library's counter-based generator (nd_seed), written to the workspace by the
+    // first node and consumed from there; the last node advances the batch counter
+    const bool draw = noise_dev == nullptr;
     StepIO io{};
     io.yhat = yhat_dev;   io.yhat_ms = (size_t)B * C;
     io.ymean = ymean_dev; io.ymean_ms = (size_t)B * C;
-    io.noise = noise_dev; io.noise_ms = (size_t)T * M * C;
+    io.noise = draw ? h->noise_ws : noise_dev; io.noise_ms = (size_t)T * M * C;
     io.y0_out = y0_out_dev; io.y0_ms = (size_t)M * C;
     io.seq_out = seq_out_dev; io.seq_ms = (size_t)(T + 1) * M * C;
     io.alphas = h->alphas; io.omabs = h->omabs;
-    if (!use_graph) {
-        Emitter em{st};
-        hipError_t e = emit_loop(h, em, m0, nm, io, B, mc, T);
-        if (e != hipSuccess) return nd_set_err(ND_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
-        return ND_OK;
-    }
+    if (!use_graph) return run_loop_eager(h, st, m0, nm, io, draw, B, mc, T);
     GraphKey key{m0, nm, B, mc, T, yhat_dev, ymean_dev, noise_dev, y0_out_dev, seq_out_dev};
     auto it = h->graphs.find(key);
     if (it == h->graphs.end()) {
         Emitter em{st};
         HIP_CHECK(hipGraphCreate(&em.graph, 0));
+        if (draw) {
+            float* out = h->noise_ws;
+            const unsigned long long* state = h->rng_state;
+            unsigned long long seed0 = 0;
+            uint32_t z0 = 0, z1 = 0;
+            int nmv = nm, Tv = T, Bv = B, mcv = mc, Cv = C;
+            void* a[] = {&out, &state, &seed0, &z0, &z1, &nmv, &Tv, &Bv, &mcv, &Cv};
+            const size_t total = (size_t)nm * T * M * ((C + 3) / 4);
+            em.emit(nd_philox_normal_kernel(), dim3((unsigned)((total + 255) / 256)), dim3(256), a);
+        }
         hipError_t e = emit_loop(h, em, m0, nm, io, B, mc, T);
+        if (e == hipSuccess && draw) {
+            unsigned long long* state = h->rng_state;
+            void* a[] = {&state};
+            em.emit(nd_rng_advance_kernel(), dim3(1), dim3(64), a);
+            e = em.err;
+        }
         if (e != hipSuccess) {
             (void)hipGraphDestroy(em.graph);
             return nd_set_err(ND_ERR_HIP, "graph build failed: %s", hipGetErrorString(e));
@@ -883,5 +939,88 @@ extern "C" int nd_sample(nd_handle h, int m0, int nm, const float* yhat_dev, con
         it = h->graphs.emplace(key, exec).first;
     }
     HIP_CHECK(hipGraphLaunch(it->second, st));
+    return ND_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The whole hot path of one test batch (classification_train_separately.py:749-794) as one call / one hipGraph:
+//   :753      compute_guiding_prediction           nd_guiding_prediction (ViT prefix + mapping MLPs + softmax, :755-758)
+//   :747      images_224_flat                      the same buffer viewed [B, D]
+//   (hoist)   xe = norm(encoder_x(x)) per member   nd_encode, once per (member, batch) instead of once per step
+//   :767-777  K members x mc trials p_sample_loop  the 3T+1 step kernels (all members and trials per launch)
+//   :786-789  vote, compute_ensemble_confidence    nd_aggregate
+// The graph is recorded by stream capture on a private stream (the caller's stream may be the legacy default stream, which
+// cannot be captured) after one eager pass, which also makes every lazily set function attribute (dynamic LDS sizes) exist
+// before the capture; it is then replayed on the caller's stream.
+// ---------------------------------------------------------------------------------------------
+static int batch_enqueue(nd_handle_s* h, nd_cond c, const float* images, const float* noise, const nd_batch_out* out, int B, int mc,
+                         int T, float temperature, hipStream_t st) {
+    const int K = h->cfg.n_members, C = h->cfg.y_dim, M = B * mc;
+    const bool draw = noise == nullptr;
+    int rc = nd_guiding_prediction(c, images, h->logits_ws, out->yhat, B, st);
+    if (rc != ND_OK) return rc;
+    rc = nd_encode(h, 0, K, images, B, st);
+    if (rc != ND_OK) return rc;
+    StepIO io{};
+    io.yhat = out->yhat;  io.yhat_ms = (size_t)B * C;
+    io.ymean = out->yhat; io.ymean_ms = (size_t)B * C;           // y_T_mean = y_0_hat (:762, quirk Q2)
+    io.noise = draw ? h->noise_ws : noise; io.noise_ms = (size_t)T * M * C;
+    io.y0_out = out->samples; io.y0_ms = (size_t)M * C;          // [K][mc*B][C] == [K*mc][B][C]: member-major, then trial
+    io.alphas = h->alphas; io.omabs = h->omabs;
+    rc = run_loop_eager(h, st, 0, K, io, draw, B, mc, T);
+    if (rc != ND_OK) return rc;
+    return nd_aggregate(out->samples, out->prob, out->vote, out->probs, K * mc, B, C, temperature, st);
+}
+
+extern "C" int nd_predict_batch(nd_handle h, nd_cond c, const float* images_dev, const float* noise_dev, const nd_batch_out* out,
+                                int B, int mc, int T, float temperature, int use_graph, void* stream) {
+    if (!h || !h->ws) return nd_set_err(ND_ERR_STATE, "workspace not bound");
+    if (!c) return nd_set_err(ND_ERR_ARG, "conditioner is NULL");
+    if (!images_dev || !out || !out->samples || !out->prob || !out->vote || !out->yhat) return nd_set_err(ND_ERR_ARG, "NULL tensor");
+    const nd_cond_config* cc = nd_cond_get_config(c);
+    const nd_config& g = h->cfg;
+    if (cc->n_mlps != g.n_members) return nd_set_err(ND_ERR_ARG, "conditioner has %d mapping MLPs, ensemble %d members", cc->n_mlps, g.n_members);
+    if (cc->num_classes != g.y_dim) return nd_set_err(ND_ERR_ARG, "conditioner has %d classes, ensemble %d", cc->num_classes, g.y_dim);
+    if ((long)cc->in_chans * cc->img_size * cc->img_size != g.data_dim)
+        return nd_set_err(ND_ERR_ARG, "image size %dx%dx%d != data_dim %d", cc->in_chans, cc->img_size, cc->img_size, g.data_dim);
+    int rc = check_range(h, 0, g.n_members);
+    if (rc != ND_OK) return rc;
+    if (B < 1 || B > g.max_batch || B > cc->max_batch) return nd_set_err(ND_ERR_ARG, "B=%d outside [1,%d]", B, g.max_batch < cc->max_batch ? g.max_batch : cc->max_batch);
+    if (mc < 1 || (long)B * mc > g.max_rows) return nd_set_err(ND_ERR_ARG, "B*mc=%ld exceeds max_rows=%d", (long)B * mc, g.max_rows);
+    if (T < 1 || T > g.n_steps) return nd_set_err(ND_ERR_ARG, "T=%d outside [1,%d]", T, g.n_steps);
+    if (h->sched_T < T) return nd_set_err(ND_ERR_STATE, "schedule holds %d steps, need %d (nd_set_schedule)", h->sched_T, T);
+    if (!(temperature > 0.f)) return nd_set_err(ND_ERR_ARG, "temperature must be > 0");
+    hipStream_t st = (hipStream_t)stream;
+    if (!use_graph) return batch_enqueue(h, c, images_dev, noise_dev, out, B, mc, T, temperature, st);
+    unsigned tb;
+    memcpy(&tb, &temperature, sizeof tb);
+    BatchKey key{c, images_dev, noise_dev, out->samples, out->prob, out->vote, out->probs, out->yhat, B, mc, T, tb, h->profiling};
+    auto it = h->batch_graphs.find(key);
+    if (it == h->batch_graphs.end()) {
+        // first call of this shape: one eager pass on the caller's stream IS this call's result; the graph recorded next to it is
+        // for the following calls
+        rc = batch_enqueue(h, c, images_dev, noise_dev, out, B, mc, T, temperature, st);
+        if (rc != ND_OK) return rc;
+        if (!h->capture_stream) HIP_CHECK(hipStreamCreateWithFlags(&h->capture_stream, hipStreamNonBlocking));
+        HIP_CHECK(hipStreamBeginCapture(h->capture_stream, hipStreamCaptureModeRelaxed));
+        rc = batch_enqueue(h, c, images_dev, noise_dev, out, B, mc, T, temperature, h->capture_stream);
+        hipGraph_t graph = nullptr;
+        hipError_t e = hipStreamEndCapture(h->capture_stream, &graph);
+        if (rc != ND_OK) {
+            if (graph) (void)hipGraphDestroy(graph);
+            return rc;
+        }
+        if (e != hipSuccess) return nd_set_err(ND_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
+        hipGraphExec_t exec;
+        e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (e != hipSuccess) return nd_set_err(ND_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e));
+        if (h->batch_graphs.size() >= 16) drop_graphs(h);
+        h->batch_graphs.emplace(key, exec);
+        h->encoded_B = B;
+        return ND_OK;
+    }
+    HIP_CHECK(hipGraphLaunch(it->second, st));
+    h->encoded_B = B;
     return ND_OK;
 }
