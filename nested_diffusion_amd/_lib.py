@@ -59,6 +59,33 @@ class NdMemberWeights(C.Structure):
     _fields_ = [(n, C.c_void_p) for n, _ in MEMBER_WEIGHT_FIELDS]
 
 
+class NdCondConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("img_size", "patch", "in_chans", "embed_dim", "num_heads", "mlp_hidden", "n_blocks", "n_mlps")] + \
+               [("mlp_widths", C.c_int32 * 3)] + \
+               [(n, C.c_int32) for n in ("num_classes", "max_batch", "max_tokens", "operand_dtype")] + [("ln_eps", C.c_float)]
+
+
+class NdPatchEmbedWeights(C.Structure):
+    _fields_ = [("proj_w", C.c_void_p), ("proj_b", C.c_void_p)]
+
+
+VIT_BLOCK_FIELDS = [("norm1_w", "norm1.weight"), ("norm1_b", "norm1.bias"), ("qkv_w", "attn.qkv.weight"), ("qkv_b", "attn.qkv.bias"),
+                    ("proj_w", "attn.proj.weight"), ("proj_b", "attn.proj.bias"), ("norm2_w", "norm2.weight"), ("norm2_b", "norm2.bias"),
+                    ("fc1_w", "mlp.fc1.weight"), ("fc1_b", "mlp.fc1.bias"), ("fc2_w", "mlp.fc2.weight"), ("fc2_b", "mlp.fc2.bias")]
+
+
+class NdVitBlockWeights(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n, _ in VIT_BLOCK_FIELDS]
+
+
+class NdMlpWeights(C.Structure):
+    _fields_ = [("w_packed", C.c_void_p * 4), ("bias", C.c_void_p * 4)]
+
+
+class NdBatchOut(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("samples", "prob", "vote", "probs", "yhat")]
+
+
 # every symbol include/nested_diffusion.h declares: name -> (restype, argtypes)
 _vp, _i, _sz, _f = C.c_void_p, C.c_int, C.c_size_t, C.c_float
 SIGNATURES = {
@@ -78,6 +105,20 @@ SIGNATURES = {
     "nd_profile_read": (_i, [_vp, C.POINTER(C.c_float), C.POINTER(_i)]),
     "nd_resident_weight_bytes": (C.c_longlong, [_vp, _i]),
     "nd_member_buffer": (_i, [_vp, _i, _i, _vp, _i, _vp]),
+    "nd_seed": (_i, [_vp, C.c_uint64, C.c_uint32]),
+    "nd_philox_normal": (_i, [_vp, _i, _i, _i, _i, _i, C.c_uint64, C.c_uint32, C.c_uint32, _vp]),
+    "nd_philox_raw": (_i, [_vp, _vp, _i, C.c_uint32, C.c_uint32, _vp]),
+    "nd_cond_workspace_bytes": (_sz, [C.POINTER(NdCondConfig)]),
+    "nd_cond_create": (_i, [C.POINTER(NdCondConfig), C.POINTER(_vp)]),
+    "nd_cond_destroy": (_i, [_vp]),
+    "nd_cond_get_config": (C.POINTER(NdCondConfig), [_vp]),
+    "nd_cond_bind_workspace": (_i, [_vp, _vp, _sz]),
+    "nd_cond_set_patch_embed": (_i, [_vp, C.POINTER(NdPatchEmbedWeights)]),
+    "nd_cond_set_block": (_i, [_vp, _i, C.POINTER(NdVitBlockWeights)]),
+    "nd_cond_set_mlp": (_i, [_vp, _i, C.POINTER(NdMlpWeights)]),
+    "nd_vit_block": (_i, [_vp, _i, _vp, _vp, _i, _i, _vp]),
+    "nd_guiding_prediction": (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
+    "nd_predict_batch": (_i, [_vp, _vp, _vp, _vp, C.POINTER(NdBatchOut), _i, _i, _i, _f, _i, _vp]),
     "nd_packed_bytes": (_sz, [_i, _i, _i]),
     "nd_pack_rows": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "nd_linear_workspace_bytes": (_sz, [_i, _i, _i, _i]),

@@ -9,7 +9,7 @@ from typing import Dict, Optional, Sequence, Tuple
 import torch
 
 from . import _lib
-from ._lib import MEMBER_WEIGHT_FIELDS, NdConfig, NdMemberWeights, check, ptr
+from ._lib import MEMBER_WEIGHT_FIELDS, NdBatchOut, NdConfig, NdMemberWeights, check, ptr
 
 
 def _require_gpu(device) -> torch.device:
@@ -50,6 +50,7 @@ class EnsembleEngine:
         self._weights: Dict[int, Dict[str, torch.Tensor]] = {}
         self._sched: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
         self._static: Dict[tuple, Dict[str, torch.Tensor]] = {}
+        self._batch_static: Dict[tuple, Dict[str, torch.Tensor]] = {}
 
     def __del__(self):
         try:
@@ -102,6 +103,12 @@ class EnsembleEngine:
             raise ValueError("alphas and one_minus_alphas_bar_sqrt differ in length")
         self._sched = (a, s)
         check(self.lib.nd_set_schedule(self.h, ptr(a), ptr(s), a.numel(), self._stream()), "nd_set_schedule")
+
+    def seed(self, seed: int, first_image: int = 0) -> None:
+        """Seed the in-library noise generator (used when no noise tensor is passed): Philox keyed on (seed; global image index,
+        member, trial, draw, batch counter).  `first_image` = global index of this rank's first image, so the draws of an image
+        do not depend on how the batch is sharded.  Resets the batch counter."""
+        check(self.lib.nd_seed(self.h, int(seed) & 0xFFFFFFFFFFFFFFFF, int(first_image) & 0xFFFFFFFF), "nd_seed")
 
     # -- compute -----------------------------------------------------------------------------
     def encode(self, x: torch.Tensor, member0: int = 0, n_members: Optional[int] = None) -> None:
@@ -186,12 +193,12 @@ class EnsembleEngine:
             self._static[key] = buf
         return buf
 
-    def sample(self, yhat: torch.Tensor, ymean: torch.Tensor, noise: torch.Tensor, member0: int = 0,
+    def sample(self, yhat: torch.Tensor, ymean: torch.Tensor, noise: Optional[torch.Tensor], member0: int = 0,
                n_members: Optional[int] = None, mc: int = 1, T: Optional[int] = None, return_seq: bool = False,
                use_graph: bool = True) -> torch.Tensor:
         """p_sample_loop for a member range x mc trials (diffusion_utils.py:133-163).
-        yhat, ymean: [n_members, B, C]; noise: [n_members, T, B*mc, C] in the reference's draw order.
-        Returns y_0 [n_members, B*mc, C] (or the whole trajectory [n_members, T+1, B*mc, C])."""
+        yhat, ymean: [n_members, B, C]; noise: [n_members, T, B*mc, C] in the reference's draw order, or None: the library draws
+        it (Philox, see seed()).  Returns y_0 [n_members, B*mc, C] (or the whole trajectory [n_members, T+1, B*mc, C])."""
         n_members = self.K - member0 if n_members is None else n_members
         T = self.T if T is None else T
         if yhat.dim() != 3 or yhat.shape[0] != n_members or yhat.shape[2] != self.C:
@@ -200,18 +207,63 @@ class EnsembleEngine:
         M = B * mc
         if tuple(ymean.shape) != tuple(yhat.shape):
             raise ValueError("ymean must have yhat's shape")
-        if tuple(noise.shape) != (n_members, T, M, self.C):
+        if noise is not None and tuple(noise.shape) != (n_members, T, M, self.C):
             raise ValueError(f"noise must be [{n_members}, {T}, {M}, {self.C}], got {tuple(noise.shape)}")
         if use_graph:
             buf = self.static_buffers(n_members, B, mc, T, return_seq)
-            buf["yhat"].copy_(yhat); buf["ymean"].copy_(ymean); buf["noise"].copy_(noise)
-            yh, ym, nz, y0 = buf["yhat"], buf["ymean"], buf["noise"], buf["y0"]
+            buf["yhat"].copy_(yhat); buf["ymean"].copy_(ymean)
+            if noise is not None:
+                buf["noise"].copy_(noise)
+            yh, ym, nz, y0 = buf["yhat"], buf["ymean"], (buf["noise"] if noise is not None else None), buf["y0"]
             seq = buf.get("seq")
         else:
-            yh, ym, nz = self._dev(yhat), self._dev(ymean), self._dev(noise)
+            yh, ym, nz = self._dev(yhat), self._dev(ymean), (self._dev(noise) if noise is not None else None)
             y0 = torch.empty(n_members, M, self.C, device=self.device)
             seq = torch.empty(n_members, T + 1, M, self.C, device=self.device) if return_seq else None
         check(self.lib.nd_sample(self.h, member0, n_members, ptr(yh), ptr(ym), ptr(nz), ptr(y0), ptr(seq), B, mc, T,
                                  1 if use_graph else 0, self._stream()), "nd_sample")
         out = seq if return_seq else y0
         return out.clone() if use_graph else out
+
+    # -- the whole hot path of a batch -------------------------------------------------------------
+    def batch_buffers(self, B: int, mc: int, T: int, image_shape) -> Dict[str, torch.Tensor]:
+        """Fixed-address input / output tensors of predict_batch for one (B, mc, T): the batch graph is recorded once per set.
+        buf['images'] is the input buffer: a caller that writes its batch THERE (e.g. the H2D copy of a loader) saves the
+        device-to-device copy predict_batch otherwise makes."""
+        key = (B, mc, T, tuple(image_shape))
+        buf = self._batch_static.get(key)
+        if buf is None:
+            K, C_, dev = self.K, self.C, self.device
+            buf = {"images": torch.empty(B, *image_shape, device=dev), "noise": None,
+                   "samples": torch.empty(K * mc, B, C_, device=dev), "prob": torch.empty(B, C_, device=dev),
+                   "vote": torch.empty(B, dtype=torch.int64, device=dev), "probs": torch.empty(K * mc, B, C_, device=dev),
+                   "yhat": torch.empty(K, B, C_, device=dev)}
+            self._batch_static[key] = buf
+        return buf
+
+    def predict_batch(self, cond, images: torch.Tensor, noise: Optional[torch.Tensor], mc: int, T: int, temperature: float,
+                      use_graph: bool = True, clone: bool = True) -> Dict[str, torch.Tensor]:
+        """classification_train_separately.py:749-794 for one batch in ONE library call (nd_predict_batch; one hipGraph launch
+        after the first call of a shape): guiding prediction, softmax, encoder hoist, K x mc p_sample_loops, aggregation.
+        cond: nd_cond handle (mapping.GuidingConditioner.handle).  images [B, Cin, H, W]; noise [K, T, B*mc, C] or None (Philox).
+        clone=False returns the fixed output buffers themselves (overwritten by the next call)."""
+        B = images.shape[0]
+        if images.dim() != 4 or images[0].numel() != self.D:
+            raise ValueError(f"images must be [B, Cin, H, W] with Cin*H*W = {self.D}, got {tuple(images.shape)}")
+        M = B * mc
+        buf = self.batch_buffers(B, mc, T, images.shape[1:])
+        if images.data_ptr() != buf["images"].data_ptr():
+            buf["images"].copy_(images)
+        nz = None
+        if noise is not None:
+            if tuple(noise.shape) != (self.K, T, M, self.C):
+                raise ValueError(f"noise must be [{self.K}, {T}, {M}, {self.C}], got {tuple(noise.shape)}")
+            if buf["noise"] is None:
+                buf["noise"] = torch.empty(self.K, T, M, self.C, device=self.device)
+            buf["noise"].copy_(noise)
+            nz = buf["noise"]
+        out = NdBatchOut(ptr(buf["samples"]), ptr(buf["prob"]), ptr(buf["vote"]), ptr(buf["probs"]), ptr(buf["yhat"]))
+        check(self.lib.nd_predict_batch(self.h, cond, ptr(buf["images"]), ptr(nz), C.byref(out), B, mc, T, float(temperature),
+                                        1 if use_graph else 0, self._stream()), "nd_predict_batch")
+        keys = ("samples", "vote", "prob", "probs", "yhat")
+        return {k: (buf[k].clone() if clone else buf[k]) for k in keys}

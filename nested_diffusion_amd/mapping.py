@@ -10,6 +10,7 @@ blocks are deterministic functions of their input).
 """
 from __future__ import annotations
 
+import ctypes as C
 import os
 import sys
 from typing import Dict, List, Optional, Sequence
@@ -17,6 +18,7 @@ from typing import Dict, List, Optional, Sequence
 import torch
 
 from . import _lib, ops
+from ._lib import check, ptr
 
 LN_EPS = 1e-6  # timm 0.4.12: norm_layer = partial(nn.LayerNorm, eps=1e-6)
 
@@ -109,19 +111,94 @@ class VisionTransformer:
 
 
 class GuidingConditioner:
-    """cond_pred_model {'vit', 'mlps'} of the reference runner (classification_train_separately.py:249-275)."""
+    """cond_pred_model {'vit', 'mlps'} of the reference runner (classification_train_separately.py:249-275).
+
+    compute_guiding_prediction is ONE call into the library (nd_guiding_prediction): patch_embed, the shared prefix blocks and
+    every mapping MLP are sequenced in C on the current stream.  The handle (`nd_cond`) holds pointers into the tensors of
+    `vit` and `mlps` (kept alive here) and one workspace for the activations."""
 
     def __init__(self, vit: VisionTransformer, mlps: Sequence[Classifier]):
         self.vit, self.mlps = vit, list(mlps)
-        self._side = None
+        if not self.mlps:
+            raise ValueError("at least one mapping MLP is required")
+        if len(self.mlps) > vit.depth:
+            raise ValueError(f"{len(self.mlps)} mapping MLPs need as many ViT blocks, the ViT has {vit.depth}")
+        self._h = None
+        self._key = None
+        self._ws = None
 
-    def compute_guiding_prediction(self, x: torch.Tensor, include_full_vit: bool = True, side_stream=None,
-                                   side_work=None) -> List[torch.Tensor]:
-        """classification_train_separately.py:330-348: list of K (+1) logits [B, C].
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                _lib.load().nd_cond_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
 
-        The ViT blocks are MFMA-bound, the mapping MLPs (2.5 GB of weights each) HBM-bound and independent of
-        the later blocks, so with `side_stream` the MLPs (and `side_work`, e.g. the noise estimators' encoder
-        hoist) run on a second HIP stream beside the ViT; the current stream waits for them at the end."""
+    def handle(self, B: int, img_size: int):
+        """nd_cond for batches of up to B images of img_size x img_size (created on first use, re-created when either grows)."""
+        if self._h is not None and self._key[0] >= B and self._key[1] == img_size:
+            return self._h
+        lib = _lib.load()
+        vit, m0 = self.vit, self.mlps[0]
+        if img_size % vit.patch:
+            raise ValueError(f"image size {img_size} is not a multiple of the patch size {vit.patch}")
+        n_tok = (img_size // vit.patch) ** 2
+        widths = [m0.p[f"linear{i}.weight"].N for i in (1, 2, 3)]
+        n_cls = m0.p["linear4.weight"].N
+        dt = _lib.dtype_code(vit.dtype)
+        for m in self.mlps:
+            if [m.p[f"linear{i}.weight"].N for i in (1, 2, 3)] != widths or m.p["linear4.weight"].N != n_cls \
+                    or m.in_features != n_tok * vit.embed_dim or m.p["linear1.weight"].dtype != dt:
+                raise ValueError("mapping MLPs must share one shape / dtype and read all tokens of a ViT block")
+        cfg = _lib.NdCondConfig()
+        cfg.img_size, cfg.patch, cfg.in_chans, cfg.embed_dim, cfg.num_heads = img_size, vit.patch, vit.in_chans, vit.embed_dim, vit.num_heads
+        cfg.mlp_hidden = vit.p["blocks.0.mlp.fc1.weight"].shape[0]
+        cfg.n_blocks, cfg.n_mlps = vit.depth, len(self.mlps)
+        cfg.mlp_widths[0], cfg.mlp_widths[1], cfg.mlp_widths[2] = widths
+        cfg.num_classes, cfg.max_batch, cfg.max_tokens, cfg.operand_dtype, cfg.ln_eps = n_cls, max(B, 1), n_tok + 1, dt, LN_EPS
+        h = C.c_void_p()
+        check(lib.nd_cond_create(C.byref(cfg), C.byref(h)), "nd_cond_create")
+        nbytes = lib.nd_cond_workspace_bytes(C.byref(cfg))
+        ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=vit.device)
+        check(lib.nd_cond_bind_workspace(h, (ws.data_ptr() + 255) & ~255, nbytes), "nd_cond_bind_workspace")
+        pe = _lib.NdPatchEmbedWeights(vit.pe_w.data_ptr(), vit.p["patch_embed.proj.bias"].data_ptr())
+        check(lib.nd_cond_set_patch_embed(h, C.byref(pe)), "nd_cond_set_patch_embed")
+        for i in range(vit.depth):
+            w = _lib.NdVitBlockWeights()
+            for field, key in _lib.VIT_BLOCK_FIELDS:
+                setattr(w, field, vit.p[f"blocks.{i}.{key}"].data_ptr())
+            check(lib.nd_cond_set_block(h, i, C.byref(w)), "nd_cond_set_block")
+        for i, m in enumerate(self.mlps):
+            w = _lib.NdMlpWeights()
+            for l in range(4):
+                w.w_packed[l] = m.p[f"linear{l + 1}.weight"].data.data_ptr()
+                w.bias[l] = m.p[f"linear{l + 1}.bias"].data_ptr()
+            check(lib.nd_cond_set_mlp(h, i, C.byref(w)), "nd_cond_set_mlp")
+        if self._h is not None:
+            lib.nd_cond_destroy(self._h)
+        self._h, self._key, self._ws = h, (max(B, 1), img_size), ws
+        return h
+
+    def compute_guiding_prediction(self, x: torch.Tensor, include_full_vit: bool = True) -> List[torch.Tensor]:
+        """classification_train_separately.py:330-348: list of K (+1) logits [B, C]."""
+        x = ops._f32(x, "x")
+        B, K = x.shape[0], len(self.mlps)
+        h = self.handle(B, x.shape[-1])
+        n_cls = self.mlps[0].p["linear4.weight"].N
+        logits = torch.empty(K, B, n_cls, dtype=torch.float32, device=x.device)
+        check(_lib.load().nd_guiding_prediction(h, ptr(x), ptr(logits), None, B, torch.cuda.current_stream(x.device).cuda_stream),
+              "nd_guiding_prediction")
+        out = list(logits.unbind(0))
+        if include_full_vit:
+            out.append(self.vit.forward(x))          # the never-sampled (K+1)-th element (:346, quirk Q1)
+        return out
+
+    def compute_guiding_prediction_py(self, x: torch.Tensor, include_full_vit: bool = True, side_stream=None,
+                                      side_work=None) -> List[torch.Tensor]:
+        """The same sequence launched operator by operator from Python (tests: must equal the C-level call bit for bit; tools:
+        the two-stream experiment of DESIGN 7b-6 -- with `side_stream` the HBM-bound mapping MLPs and `side_work` run beside
+        the MFMA-bound ViT blocks; measured slower, not used by the product path)."""
         B = x.shape[0]
         out: List[torch.Tensor] = [None] * len(self.mlps)
         main = torch.cuda.current_stream(x.device)

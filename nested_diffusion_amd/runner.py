@@ -94,8 +94,6 @@ class Diffusion(object):
         self._states = noise_estimator_states
         self.engine: Optional[EnsembleEngine] = None
         self.members: List[int] = []
-        self.overlap_streams = bool(int(os.environ.get("ND_OVERLAP_STREAMS", "0")))
-        self._side_stream = None
 
     # ---- conditioner -------------------------------------------------------------------------
     def compute_guiding_prediction(self, x, include_full_vit: bool = True):
@@ -141,39 +139,33 @@ class Diffusion(object):
         for slot, i in enumerate(self.members):
             self.engine.load_member(slot, self._states[i])
         self.engine.set_schedule(self.alphas, self.one_minus_alphas_bar_sqrt)
+        self.engine.seed(self.seed or 0, first_image=0)          # in-library noise (predict_batch without a noise tensor)
         self._states = None            # device copies live in the engine
 
     # ---- the hot path (:749-794) --------------------------------------------------------------
     @torch.no_grad()
-    def predict_batch(self, images_224: torch.Tensor, noise: Optional[torch.Tensor] = None, mc_trials: Optional[int] = None):
+    def predict_batch(self, images_224: torch.Tensor, noise: Optional[torch.Tensor] = None, mc_trials: Optional[int] = None,
+                      clone: bool = True, use_graph: bool = True):
         """images [B,3,224,224] on the GPU -> dict(samples [K*mc, B, C] raw y_0 member-major then trial,
-        vote [B], prob [B, C], probs [K*mc, B, C]).  noise: optional [K, T, B*mc, C] in reference draw order
-        (row = trial*B + image)."""
+        vote [B], prob [B, C], probs [K*mc, B, C], yhat [K, B, C]).  noise: optional [K, T, B*mc, C] in reference draw order
+        (row = trial*B + image); None = drawn inside the library (the reference draws inside its loop, diffusion_utils.py:67,139).
+        ONE library call: the conditioner (:753), the softmax (:755-758), the encoder hoist, the K x mc sampling loops
+        (:767-777) and the aggregation (:786-789) are one hipGraph launch after the first batch of a shape."""
         if self.engine is None:
             raise RuntimeError("call load_noise_estimators() first")
+        if self.members != list(range(len(self.members))) or len(self.members) != len(self.cond_pred_model.mlps):
+            raise RuntimeError(f"member k is conditioned on mapping MLP k: {len(self.cond_pred_model.mlps)} MLPs need as many "
+                               f"noise estimators, {len(self.members)} are loaded")
         mc = mc_trials or self.mc_trials
-        eng, K, T = self.engine, len(self.members), self.num_timesteps
-        B = images_224.shape[0]
-        C = self.config.data.num_classes
-        images_224_flat = torch.flatten(images_224, 1)                                  # :747
-        if self._side_stream is None and self.overlap_streams:
-            self._side_stream = torch.cuda.Stream(self.device)
-        # :753 (6th element never sampled).  The encoder hoist and the mapping MLPs stream weights from HBM while
-        # the ViT blocks keep the matrix cores busy: they run on a second stream beside the ViT.
-        logits = self.cond_pred_model.compute_guiding_prediction(
-            images_224, include_full_vit=False, side_stream=self._side_stream if self.overlap_streams else None,
-            side_work=lambda: eng.encode(images_224_flat))
-        yhat = torch.stack([ops.softmax_rows(logits[i]) for i in self.members])         # :755-758, [K,B,C]
-        if noise is None:
-            noise = torch.randn(K, T, B * mc, C, device=self.device)
-        y0 = eng.sample(yhat, yhat, noise, mc=mc, T=T)                                  # :767-777 (y_T_mean = yhat, Q2)
-        samples = y0.reshape(K * mc, B, C)                                              # member-major, then trial
-        prob, vote, probs = ops.aggregate(samples, self.temperature, return_probs=True)  # :786, :789
-        return {"samples": samples, "vote": vote, "prob": prob, "probs": probs, "yhat": yhat}
+        eng, T = self.engine, self.num_timesteps
+        images_224 = ops._f32(images_224, "images")
+        cond = self.cond_pred_model.handle(images_224.shape[0], images_224.shape[-1])
+        return eng.predict_batch(cond, images_224, noise, mc, T, self.temperature, use_graph=use_graph, clone=clone)
 
     # ---- world-size independent randomness ---------------------------------------------------------
     def draw_noise(self, B_total: int, lo: int, hi: int, mc: Optional[int] = None) -> torch.Tensor:
-        """The sampler's draws for rows [lo, hi) of a test batch of B_total images: [K, T, (hi-lo)*mc, C].
+        """torch-generator draws for rows [lo, hi) of a test batch of B_total images: [K, T, (hi-lo)*mc, C], for callers that want
+        explicit noise (test_atk itself uses the library's generator, which has the same property at no cost).
         Every rank holds the same --seed (the reference's set_seed, :31-38), draws the draws of the WHOLE batch
         [K, T, mc, B_total, C] and keeps its own images, so image i sees the same K*T*mc draws at any world size
         (and rows of different ranks are not copies of each other)."""
@@ -206,10 +198,11 @@ class Diffusion(object):
             lo, hi = nd_dist.shard_bounds(B, rank, world)
             if self.engine is None:
                 self.load_noise_estimators(max_batch=max(hi - lo, 1))
+            self.engine.seed(self.seed or 0, first_image=lo)
             samples, targets = [], []
             for images_raw, target in test_loader:
                 images = self.shard_of_batch(images_raw, lo, hi)
-                out = self.predict_batch(images, noise=self.draw_noise(images_raw.shape[0], lo, hi))
+                out = self.predict_batch(images)
                 S = out["samples"].shape[0]
                 flat = out["samples"].permute(1, 0, 2).reshape(hi - lo, -1).contiguous()      # [B_local, S*C]
                 flat = nd_dist.all_gather_rows(flat, B, world)
@@ -257,11 +250,14 @@ class Diffusion(object):
         B = config.testing.batch_size
         lo, hi = nd_dist.shard_bounds(B, rank, world)
         self.load_noise_estimators(max_batch=max(hi - lo, 1))
+        # the sampler's draws come from the library's counter-based generator keyed on the GLOBAL image index (lo = this rank's
+        # first image) and the batch counter: image i sees the same K*T*mc draws at any world size
+        self.engine.seed(self.seed or 0, first_image=lo)
         mv_class, target_class, prob_mc, piw_mc, var_mc = [], [], [], [], []
         n_step_img, t0 = 0, time.time()
         for images_raw, target in test_loader:
             images = self.shard_of_batch(images_raw, lo, hi)                 # :726-737
-            out = self.predict_batch(images, noise=self.draw_noise(images_raw.shape[0], lo, hi))
+            out = self.predict_batch(images, clone=False)
             # spread of the K*mc per-sample probabilities per image (what the reference keeps in pred_mc, quirk Q4)
             piw, var = ops.sample_stats(out["probs"])
             packed = torch.cat([out["prob"], piw, var, out["vote"].to(torch.float32)[:, None]], dim=1)

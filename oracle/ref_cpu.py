@@ -591,3 +591,40 @@ def crop_and_resize(images: Tensor, corners, crop: int) -> Tensor:
         c = images[b:b + 1, :, top:top + crop, left:left + crop]
         outs.append(F.interpolate(c, size=(H, W), mode="bilinear", align_corners=False)[0])
     return torch.stack(outs)
+
+
+# ----------------------------------------------------------------------------
+# in-library noise of the throughput mode (NO reference counterpart: the reference draws with torch's global CPU/CUDA
+# generator, diffusion_utils.py:67,139).  Restatement of Philox4x32-10 (Salmon et al., SC'11; Random123) and of the
+# Box-Muller mapping csrc/nd_rng.hip uses, for known-answer and bit-level checks of the HIP generator.
+# ----------------------------------------------------------------------------
+def philox4x32_10(ctr, key0: int, key1: int):
+    """ctr: uint32 array [n, 4] -> uint32 [n, 4]."""
+    import numpy as np
+    c = np.array(ctr, dtype=np.uint64).reshape(-1, 4).copy()
+    k0, k1 = np.uint64(key0), np.uint64(key1)
+    M0, M1, W0, W1, MASK = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), np.uint64(0x9E3779B9), np.uint64(0xBB67AE85), np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0, p1 = M0 * c[:, 0], M1 * c[:, 2]
+        hi0, lo0, hi1, lo1 = p0 >> np.uint64(32), p0 & MASK, p1 >> np.uint64(32), p1 & MASK
+        c = np.stack([hi1 ^ c[:, 1] ^ k0, lo1, hi0 ^ c[:, 3] ^ k1, lo0], axis=1)
+        k0, k1 = (k0 + W0) & MASK, (k1 + W1) & MASK
+    return c.astype(np.uint32)
+
+
+def philox_normal(n_members: int, T: int, B: int, mc: int, C: int, seed: int, batch_counter: int = 0, first_image: int = 0) -> Tensor:
+    """[n_members, T, mc*B, C] standard normals, row = trial*B + image: counter = (first_image + image, trial | member << 16 |
+    class-quad << 24, draw index, batch counter), key = seed; Box-Muller on (x0, x1) and (x2, x3) in float64."""
+    import numpy as np
+    Q = (C + 3) // 4
+    k, i, trial, b, q = np.meshgrid(np.arange(n_members), np.arange(T), np.arange(mc), np.arange(B), np.arange(Q), indexing="ij")
+    ctr = np.stack([(first_image + b) & 0xFFFFFFFF, trial | (k << 16) | (q << 24), i, np.full_like(i, batch_counter & 0xFFFFFFFF)], axis=-1)
+    x = philox4x32_10(ctr.reshape(-1, 4), seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF).astype(np.float64)
+    two32 = 4294967296.0
+    u1 = np.minimum((x[:, [0, 2]].astype(np.float32).astype(np.float64) + 1.0), two32) / two32      # as the kernel: float(x) + 1, fp32
+    u2 = x[:, [1, 3]].astype(np.float32).astype(np.float64) / two32
+    r = np.sqrt(-2.0 * np.log(u1))
+    z = np.stack([r[:, 0] * np.cos(2 * np.pi * u2[:, 0]), r[:, 0] * np.sin(2 * np.pi * u2[:, 0]),
+                  r[:, 1] * np.cos(2 * np.pi * u2[:, 1]), r[:, 1] * np.sin(2 * np.pi * u2[:, 1])], axis=1)
+    z = z.reshape(n_members, T, mc * B, Q * 4)[..., :C]
+    return torch.from_numpy(z.astype(np.float32))

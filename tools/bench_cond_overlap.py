@@ -38,11 +38,11 @@ def side_only():
 
 
 def serial():
-    return cond.compute_guiding_prediction(x, include_full_vit=False, side_work=lambda: eng.encode(xf))
+    return cond.compute_guiding_prediction_py(x, include_full_vit=False, side_work=lambda: eng.encode(xf))
 
 
 def two_streams():
-    return cond.compute_guiding_prediction(x, include_full_vit=False, side_stream=side, side_work=lambda: eng.encode(xf))
+    return cond.compute_guiding_prediction_py(x, include_full_vit=False, side_stream=side, side_work=lambda: eng.encode(xf))
 
 
 def timeit(fn, reps=10):

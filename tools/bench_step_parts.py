@@ -25,7 +25,7 @@ def timed(fn, reps=20):
 
 
 t_all, out = timed(lambda: runner.predict_batch(images))
-t_cond, logits = timed(lambda: runner.cond_pred_model.compute_guiding_prediction(images, include_full_vit=False, side_work=lambda: eng.encode(flat)))
+t_cond, logits = timed(lambda: runner.cond_pred_model.compute_guiding_prediction_py(images, include_full_vit=False, side_work=lambda: eng.encode(flat)))
 t_soft, yhat = timed(lambda: torch.stack([ops.softmax_rows(logits[i]) for i in runner.members]))
 t_rand, noise = timed(lambda: torch.randn(K, T, B, C, device=dev))
 t_samp, y0 = timed(lambda: eng.sample(yhat, yhat, noise, mc=1, T=T))
