@@ -101,7 +101,7 @@ def test_sampler_draws_its_own_noise_and_advances_the_batch_counter():
     assert not torch.equal(eng.sample(yhat, yhat, None, mc=mc), a0)
 
 
-def _vit_and_mlps(embed=128, heads=2, depth=5, img=32, patch=16, K=5, widths=(64, 32, 16), seed=3):
+def _vit_and_mlps(embed=128, heads=2, depth=5, img=32, patch=16, K=5, widths=(64, 32, 32), seed=3):
     vp = ref_cpu.init_vit_params(embed=embed, depth=depth, patch=patch, img=img, seed=seed)
     n_tok = (img // patch) ** 2
     mlps = [ref_cpu.init_classifier_params(n_tok * embed, widths=widths, seed=20 + i) for i in range(K)]

@@ -77,10 +77,14 @@ def test_main_test_path_end_to_end(tmp_path, capsys, monkeypatch):
     assert "Testing procedure finished" in txt2 and "Traceback" not in txt2, txt2
 
 
-def test_main_swallows_errors_like_the_reference(tmp_path, capsys):
+def test_main_swallows_errors_like_the_reference(tmp_path, capsys, monkeypatch):
     """main.py:377-380: any exception is logged with a traceback and the process still returns 0."""
     from nested_diffusion_amd import main as nd_main
-    ypath, *_ = _write_run(str(tmp_path))
+    from nested_diffusion_amd import mapping
+    import nested_diffusion_amd.runner as runner_mod
+    ypath, _, _, _, dims = _write_run(str(tmp_path))
+    orig = mapping.load_conditioner          # the tiny ViT of this test has 2 heads of 64; the loader's default is 12
+    monkeypatch.setattr(runner_mod, "load_conditioner", lambda path, ds, device="cuda", num_heads=12, dtype="f32": orig(path, ds, device, dims["heads"], dtype))
     argv = ["--test", "--loss", "card_onehot_conditional", "--config", ypath, "--exp", os.path.join(str(tmp_path), "r"), "--doc", "d",
             "--ni", "--preprocess", "grayscaled", "--timesteps", "6", "--attack_name", "FGSM", "--eps", "0.03", "--synthetic_batches", "1"]
     assert nd_main.main(argv) == 0
