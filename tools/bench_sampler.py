@@ -1,5 +1,6 @@
 """Sampler-only timing (K members x T steps in one hipGraph) with the in-graph kernel probes.  GPU only.
-   [ND_DTYPE=f16] python tools/bench_sampler.py [K T B mc]"""
+   [ND_DTYPE=f16] [ND_BENCH_F=4080] python tools/bench_sampler.py [K T B mc]
+   ND_BENCH_F: feature dim (4080 = 255 fragments per member = exactly 5 per workgroup at K = 5: what perfect balance is worth)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -8,7 +9,7 @@ from nested_diffusion_amd.engine import EnsembleEngine
 from nested_diffusion_amd.diffusion_utils import make_beta_schedule
 
 K, T, B, mc = (int(v) for v in (sys.argv[1:5] + ["5", "100", "32", "1"][len(sys.argv) - 1:]))
-D, H, F, C = 1024, 4096, 4096, 2     # the step loop never touches data_dim: a small encoder keeps set-up short
+D, H, F, C = 1024, 4096, int(os.environ.get("ND_BENCH_F", "4096")), 2     # the step loop never touches data_dim: a small encoder keeps set-up short
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
 DT = os.environ.get("ND_DTYPE", "f32")
