@@ -1,0 +1,40 @@
+"""The five GEMM shapes of one ViT-B/16 block at B = 32 (M = 6272 token rows), with their epilogues, timed through nd_gemm_bias_act.
+   python tools/bench_gemm_vit.py [B]      -> us and TFLOP/s per shape (back-to-back launches of ONE shape: the matrix pipe is busy
+   throughout, so the clock settles lower than inside the conditioner, where GEMMs alternate with LayerNorm / attention), block total,
+   relative error against an fp64 product.  profiles/r03_gemm_tile_width_experiment.txt: this script on a build whose plan could also
+   pick 128 x 128 tiles (ND_GEMM_BN): 874 us per block against 856-865 us with 128 x 64 -- not kept."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from nested_diffusion_amd import ops
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+M = B * 196
+g = torch.Generator(device="cuda").manual_seed(0)
+shapes = [("patch_embed", 768, 768, None, False), ("qkv", 768, 2304, None, False), ("proj", 768, 768, None, True),
+          ("fc1", 768, 3072, "gelu", False), ("fc2", 3072, 768, None, True)]
+tot = 0.0
+for name, K, N, act, res in shapes:
+    x = torch.randn(M, K, device="cuda", generator=g)
+    w = torch.randn(N, K, device="cuda", generator=g) / K ** 0.5
+    b = torch.randn(N, device="cuda", generator=g)
+    r = torch.randn(M, N, device="cuda", generator=g) if res else None
+    for _ in range(3):
+        y = ops.gemm_bias_act(x, w, b, act=act, residual=r)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); e0.record()
+    reps = 30
+    for _ in range(reps):
+        y = ops.gemm_bias_act(x, w, b, act=act, residual=r)
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / reps * 1e3
+    ref = torch.nn.functional.linear(x.double(), w.double(), b.double())
+    if act == "gelu":
+        ref = torch.nn.functional.gelu(ref)
+    if res:
+        ref = ref + r.double()
+    err = float((y.double() - ref).abs().max() / ref.abs().max())
+    if name != "patch_embed":
+        tot += us
+    print(f"{name:12s} M={M} K={K:4d} N={N:4d}: {us:7.1f} us  {2 * M * K * N / us / 1e6:6.1f} TFLOP/s  rel err vs fp64 {err:.1e}", flush=True)
+print(f"block GEMMs (qkv+proj+fc1+fc2): {tot:.1f} us")
