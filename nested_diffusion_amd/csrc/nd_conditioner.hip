@@ -9,13 +9,19 @@
 //
 // Nothing here allocates or synchronises, so a call can be captured into a hipGraph (nd_predict_batch does).
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <vector>
 #include <cstring>
 #include "../../include/nested_diffusion.h"
 
 int nd_set_err(int code, const char* fmt, ...);
 
+static std::atomic<unsigned long long> g_cond_serial{1};
+
 struct nd_cond_s {
+    // changes whenever anything a recorded launch sequence depends on changes (creation, workspace, any weight pointer): graphs
+    // recorded against an older value must not be replayed (a freed handle's address can be handed out again by the allocator)
+    unsigned long long serial = g_cond_serial.fetch_add(1);
     nd_cond_config cfg{};
     nd_patch_embed_weights pe{};
     std::vector<nd_vit_block_weights> blocks;
@@ -116,6 +122,8 @@ extern "C" int nd_cond_create(const nd_cond_config* cfg, nd_cond* out) {
 }
 
 extern "C" const nd_cond_config* nd_cond_get_config(nd_cond c) { return c ? &c->cfg : nullptr; }
+unsigned long long nd_cond_serial(nd_cond c) { return c ? c->serial : 0; }
+static void touch(nd_cond_s* c) { c->serial = g_cond_serial.fetch_add(1); }
 
 extern "C" int nd_cond_destroy(nd_cond c) {
     delete c;
@@ -130,6 +138,7 @@ extern "C" int nd_cond_bind_workspace(nd_cond c, void* ws, size_t bytes) {
     if (bytes < need) return nd_set_err(ND_ERR_ARG, "workspace too small: %zu < %zu", bytes, need);
     c->ws = (char*)ws;
     c->ws_bytes = bytes;
+    touch(c);
     return ND_OK;
 }
 
@@ -147,6 +156,7 @@ extern "C" int nd_cond_set_patch_embed(nd_cond c, const nd_patch_embed_weights* 
     if (rc != ND_OK) return rc;
     c->pe = *w;
     c->have_pe = true;
+    touch(c);
     return ND_OK;
 }
 
@@ -157,6 +167,7 @@ extern "C" int nd_cond_set_block(nd_cond c, int block, const nd_vit_block_weight
     if (rc != ND_OK) return rc;
     c->blocks[block] = *w;
     c->have_block[block] = 1;
+    touch(c);
     return ND_OK;
 }
 
@@ -167,6 +178,7 @@ extern "C" int nd_cond_set_mlp(nd_cond c, int i, const nd_mlp_weights* w) {
     if (rc != ND_OK) return rc;
     c->mlps[i] = *w;
     c->have_mlp[i] = 1;
+    touch(c);
     return ND_OK;
 }
 

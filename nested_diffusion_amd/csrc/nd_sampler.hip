@@ -340,8 +340,11 @@ struct GraphKey {
     }
 };
 
+unsigned long long nd_cond_serial(nd_cond c);     // nd_conditioner.hip: changes with every change of the conditioner's state
+
 struct BatchKey {
-    const void *cond, *images, *noise, *samples, *prob, *vote, *probs, *yhat;
+    unsigned long long cond;          // the conditioner's serial, not its address (addresses are reused after nd_cond_destroy)
+    const void *images, *noise, *samples, *prob, *vote, *probs, *yhat;
     int B, mc, T;
     unsigned temp_bits;
     bool profiling;
@@ -994,7 +997,7 @@ extern "C" int nd_predict_batch(nd_handle h, nd_cond c, const float* images_dev,
     if (!use_graph) return batch_enqueue(h, c, images_dev, noise_dev, out, B, mc, T, temperature, st);
     unsigned tb;
     memcpy(&tb, &temperature, sizeof tb);
-    BatchKey key{c, images_dev, noise_dev, out->samples, out->prob, out->vote, out->probs, out->yhat, B, mc, T, tb, h->profiling};
+    BatchKey key{nd_cond_serial(c), images_dev, noise_dev, out->samples, out->prob, out->vote, out->probs, out->yhat, B, mc, T, tb, h->profiling};
     auto it = h->batch_graphs.find(key);
     if (it == h->batch_graphs.end()) {
         // first call of this shape: one eager pass on the caller's stream IS this call's result; the graph recorded next to it is

@@ -265,3 +265,24 @@ def test_predict_batch_argument_checks():
         r.predict_batch(torch.rand(4, 3, img, img).cuda())                 # B above max_batch
     with pytest.raises(_lib.NdError):
         r.predict_batch(x.cpu())                                           # no CPU fallback
+
+
+def test_recorded_graphs_do_not_outlive_a_replaced_conditioner():
+    """GuidingConditioner.handle() re-creates its nd_cond when the batch grows; the allocator may hand the new handle the address
+    of the destroyed one.  Batch graphs are keyed on the conditioner's serial (it changes with every state change), so a graph
+    recorded against the old handle's workspace is never replayed."""
+    K, T, B, mc, Cc = 5, 4, 4, 1, 2
+    r, (_, _, _, _, _, img) = _runner(K, T, B, mc)
+    g = torch.Generator().manual_seed(4)
+    x = torch.rand(B, 3, img, img, generator=g).cuda()
+    nz3, nz4 = torch.randn(K, T, 3, Cc, generator=g).cuda(), torch.randn(K, T, 4, Cc, generator=g).cuda()
+    for _ in range(2):
+        small = r.predict_batch(x[:3], noise=nz3)               # handle sized for 3 images; graph recorded, then replayed
+    h_small = r.cond_pred_model._h.value
+    for _ in range(2):
+        big = r.predict_batch(x, noise=nz4)                      # batch of 4: the conditioner handle is re-created
+    assert r.cond_pred_model._key[0] == 4
+    again = r.predict_batch(x[:3], noise=nz3)                    # the (B = 3) graph of the destroyed handle must not be replayed
+    assert torch.equal(again["samples"], small["samples"]) and torch.equal(again["prob"], small["prob"])
+    assert torch.equal(big["samples"], r.predict_batch(x, noise=nz4, use_graph=False)["samples"])
+    print("conditioner handle address reused:", r.cond_pred_model._h.value == h_small)
