@@ -13,8 +13,11 @@ M = B * 196
 g = torch.Generator(device="cuda").manual_seed(0)
 shapes = [("patch_embed", 768, 768, None, False), ("qkv", 768, 2304, None, False), ("proj", 768, 768, None, True),
           ("fc1", 768, 3072, "gelu", False), ("fc2", 3072, 768, None, True)]
+only = os.environ.get("ND_GEMM_ONLY")            # one shape only (tools/pmc_gemm.sh: PMC passes per shape)
 tot = 0.0
 for name, K, N, act, res in shapes:
+    if only and name != only:
+        continue
     x = torch.randn(M, K, device="cuda", generator=g)
     w = torch.randn(N, K, device="cuda", generator=g) / K ** 0.5
     b = torch.randn(N, device="cuda", generator=g)
