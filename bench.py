@@ -265,7 +265,7 @@ def main():
     for _ in range(args.warmup):
         step()
     dt, out = timed_steps(args.steps)
-    head_us, lin2_us, lin3_us, n_probe = eng.profile_read()
+    head_us, pair_us, rec_us, n_probe = eng.profile_read()
     eng.set_profiling(False)
     step()
     dt_unprobed, _ = timed_steps(args.steps)
@@ -313,8 +313,10 @@ def main():
     F = 4096
     M = B * mc
     wb = 4.0 if args.dtype == "f32" else 2.0
-    avg_us = 0.5 * (lin2_us + lin3_us) if n_probe else float("nan")
-    ovh_us = getattr(eng, "probe_overhead_us", 0.0) if n_probe else 0.0
+    # mean duration of one step-block launch: the lin2 and lin3(+lin4) launches of a probed step sit in ONE event interval; the
+    # empty interval recorded right behind it is what a record node adds to any interval
+    avg_us = 0.5 * (pair_us - rec_us) if n_probe else float("nan")
+    ovh_us = rec_us if n_probe else 0.0
     plan = eng.step_plan(M, K)
     if plan["kernel"] == "k_skinny":
         # ALGORITHMIC bytes of ONE launch of the dominant kernel (a ConditionalLinear block of all K members): weights F*F,
@@ -361,9 +363,11 @@ def main():
         roof = {"bound": "mfma", "kernel": plan["name"], "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                 "frac": (achieved / peak) if achieved else None, "alg_flop_per_launch": alg, "traffic": None}
     roof["avg_launch_us"] = avg_us
-    roof["probe"] = {"head_us": head_us, "lin2_us": lin2_us, "lin3_us": lin3_us, "record_node_us": ovh_us, "steps_probed": n_probe,
-                     "note": "HIP event-record nodes inside the timed sampler graph, on the launch stream; each interval includes the "
-                             "~3 us dispatch gap of its node (rocprofv3 begin->end durations in profiles/ are that much shorter)"}
+    roof["probe"] = {"head_interval_us": head_us, "lin2_plus_lin3_interval_us": pair_us, "record_node_us": ovh_us, "steps_probed": n_probe,
+                     "note": "HIP event-record nodes inside the timed batch graph, on the launch stream: one interval around the step head, "
+                             "ONE around the two ConditionalLinear launches, and an empty one (two record nodes back to back) that measures "
+                             "what a record node adds; avg_launch_us = (lin2_plus_lin3_interval_us - record_node_us) / 2, to be compared "
+                             "with the rocprofv3 begin->end averages of the two k_skinny / k_cond_gemm rows in profiles/"}
     line = {
         "metric": "denoising-steps*images/sec (K=5,T=100,224^2)", "value": value, "unit": "denoising-step*images/s",
         "n_gpus": world, "n_ranks_seen": n_ranks_seen,

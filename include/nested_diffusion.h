@@ -133,11 +133,11 @@ int nd_sample(nd_handle h, int member0, int n_members, const float *yhat_dev, co
               int use_graph, void *stream);
 
 /* Kernel-duration probes for the roofline report: when enabled, up to 8 denoising steps of every
- * nd_sample graph (or eager loop) get hipEvent record nodes around their three kernels on the launch
- * stream.  nd_profile_read (after the stream is synchronised) returns the mean duration in
- * microseconds of the last nd_sample's probed launches: out_us[0] step head, [1] lin2 block,
- * [2] lin3+lin4 block, [3] an EMPTY interval (two record nodes back to back): what one record node adds to every
- * interval, to be subtracted when a kernel's own duration is wanted; *n_samples = probed steps.  out_us holds 4 floats. */
+ * nd_sample / nd_predict_batch graph (or eager loop) get hipEvent record nodes on the launch stream: before the step head, after
+ * it, after the two ConditionalLinear launches, and once more right behind (an EMPTY interval).  nd_profile_read (after the stream
+ * is synchronised) returns mean intervals in microseconds over the last call's probed steps: out_us[0] step head, [1] the lin2 and
+ * lin3(+lin4) launches TOGETHER, [2] 0, [3] the empty interval = what one record node adds to any interval, to be subtracted
+ * when kernel time is wanted: mean step-block launch = (out_us[1] - out_us[3]) / 2.  *n_samples = probed steps.  out_us holds 4 floats. */
 int nd_set_profiling(nd_handle h, int enable);
 /* Weight bytes of one step launch (block 0: lin2 of all loaded members, 1: lin3) that are read with default-policy loads and so
  * stay resident in the 256 MiB Infinity Cache from step to step; the rest is streamed from HBM with nontemporal loads.  Lets the

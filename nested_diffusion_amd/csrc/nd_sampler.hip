@@ -380,7 +380,7 @@ struct nd_handle_s {
     hipStream_t capture_stream = nullptr;              // only ever used to RECORD batch graphs, never to run anything
     int encoded_B = -1;
     bool profiling = false;
-    std::vector<hipEvent_t> probe_events;   // 5 per probed step: e0 | head | e1 | lin2 | e2 | lin3 | e3 | (nothing) | e4
+    std::vector<hipEvent_t> probe_events;   // 4 per probed step: e0 | head | e1 | lin2, lin3 | e2 | (nothing) | e3
     int probe_steps = 0;
 };
 
@@ -706,15 +706,18 @@ extern "C" int nd_set_profiling(nd_handle h, int enable) {
 
 extern "C" int nd_profile_read(nd_handle h, float* out_us, int* n_samples) {
     if (!h || !out_us || !n_samples) return nd_set_err(ND_ERR_ARG, "NULL argument");
-    double acc[4] = {0, 0, 0, 0};
+    double acc[3] = {0, 0, 0};
     const int n = h->probe_steps;
     for (int s = 0; s < n; ++s)
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < 3; ++k) {
             float ms = 0.f;
-            HIP_CHECK(hipEventElapsedTime(&ms, h->probe_events[5 * s + k], h->probe_events[5 * s + k + 1]));
+            HIP_CHECK(hipEventElapsedTime(&ms, h->probe_events[4 * s + k], h->probe_events[4 * s + k + 1]));
             acc[k] += ms * 1000.0;
         }
-    for (int k = 0; k < 4; ++k) out_us[k] = n ? (float)(acc[k] / n) : 0.f;
+    out_us[0] = n ? (float)(acc[0] / n) : 0.f;      // head interval
+    out_us[1] = n ? (float)(acc[1] / n) : 0.f;      // lin2 + lin3 interval (both launches, one record node)
+    out_us[2] = 0.f;
+    out_us[3] = n ? (float)(acc[2] / n) : 0.f;      // empty interval
     *n_samples = n;
     return ND_OK;
 }
@@ -837,9 +840,9 @@ static hipError_t emit_loop(nd_handle_s* h, Emitter& em, int m0, int nm, StepIO 
     // probes: up to 8 steps spread over the loop (never step 0: its head is the cheap INIT form)
     const int want = h->profiling ? (T - 1 < 8 ? T - 1 : 8) : 0;
     const int stride = want > 0 ? (T - 1) / want : 0;
-    if ((int)h->probe_events.size() < 5 * want) {
+    if ((int)h->probe_events.size() < 4 * want) {
         const size_t old = h->probe_events.size();
-        h->probe_events.resize(5 * want);
+        h->probe_events.resize(4 * want);
         for (size_t e = old; e < h->probe_events.size(); ++e)
             if (hipEventCreate(&h->probe_events[e]) != hipSuccess) return hipErrorOutOfMemory;
     }
@@ -847,7 +850,7 @@ static hipError_t emit_loop(nd_handle_s* h, Emitter& em, int m0, int nm, StepIO 
     for (int i = 0; i < T; ++i) {
         int t = T - 1 - i, t_prev = t + 1, mode = (i == 0) ? ND_HEAD_INIT : ND_HEAD_UPDATE, istep = i;
         const bool probe = want > 0 && i >= 1 && probed < want && ((i - 1) % stride) == stride / 2;
-        hipEvent_t* ev = probe ? &h->probe_events[5 * probed] : nullptr;
+        hipEvent_t* ev = probe ? &h->probe_events[4 * probed] : nullptr;
         if (probe) em.record(ev[0]);
         void* ah[] = {&mi, &mdev, &io, &mode, &istep, &t_prev, &t, &B, &M, &maxM, &F, &NT, &Tn};
         em.emit(head_fn(C), ghead, dim3(256), ah);
@@ -856,18 +859,18 @@ static hipError_t emit_loop(nd_handle_s* h, Emitter& em, int m0, int nm, StepIO 
             void* a2[] = {&d0, &t2, &M, &t, &tp.TM, &tp.TN, &tp.n_full, &tp.split, &tws};
             em.emit(nd_cond_gemm_kernel(0), tgrid, dim3(256), a2, nd_cond_gemm_dynlds());
             if (tp.rem > 0) em.emit(nd_cond_gemm_fixup_kernel(0), tfix, dim3(64), a2);
-            if (probe) em.record(ev[2]);
             void* a3[] = {&d0, &t3, &M, &t, &tp.TM, &tp.TN, &tp.n_full, &tp.split, &tws};
             em.emit(nd_cond_gemm_kernel(1), tgrid, dim3(256), a3, nd_cond_gemm_dynlds());
             if (tp.rem > 0) em.emit(nd_cond_gemm_fixup_kernel(1), tfix, dim3(64), a3);
         } else {
             void* a2[] = {&i2, &s2, &nm, &M, &t, &cps2};
             em.emit(L2.fn, L2.grid, L2.block, a2);
-            if (probe) em.record(ev[2]);
             void* a3[] = {&i3, &s3, &nm, &M, &t, &cps3};
             em.emit(L3.fn, L3.grid, L3.block, a3);
         }
-        if (probe) { em.record(ev[3]); em.record(ev[4]); ++probed; }     // e3 -> e4 brackets nothing: the cost of a record node itself
+        // the two ConditionalLinear launches share ONE interval (one record node for two kernels: half the distortion per launch);
+        // e2 -> e3 brackets nothing: what a record node itself adds to an interval
+        if (probe) { em.record(ev[2]); em.record(ev[3]); ++probed; }
     }
     h->probe_steps = probed;
     int eps_only = 0, par_cur = (T - 1) & 1;

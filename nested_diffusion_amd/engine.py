@@ -152,14 +152,15 @@ class EnsembleEngine:
         check(self.lib.nd_set_profiling(self.h, 1 if enable else 0), "nd_set_profiling")
 
     def profile_read(self):
-        """(head_us, lin2_us, lin3_us, n_probed_steps) of the last sample(); synchronises the stream.
-        self.probe_overhead_us = the measured empty interval (cost of a record node), included in all three."""
+        """(head_us, pair_us, record_us, n_probed_steps) of the last sample() / predict_batch(); synchronises the stream.
+        head_us: interval around the step head; pair_us: ONE interval around the two ConditionalLinear launches (lin2, lin3+lin4);
+        record_us: the empty interval (what a record node adds to any interval).  Mean step-block launch = (pair_us - record_us) / 2."""
         torch.cuda.current_stream(self.device).synchronize()
         us = (C.c_float * 4)()
         n = C.c_int(0)
         check(self.lib.nd_profile_read(self.h, us, C.byref(n)), "nd_profile_read")
         self.probe_overhead_us = float(us[3])
-        return float(us[0]), float(us[1]), float(us[2]), int(n.value)
+        return float(us[0]), float(us[1]), float(us[3]), int(n.value)
 
     def resident_weight_bytes(self) -> Tuple[int, int]:
         """(lin2, lin3) weight bytes per step launch that are kept Infinity-Cache resident across steps."""

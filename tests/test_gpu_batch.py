@@ -286,3 +286,23 @@ def test_recorded_graphs_do_not_outlive_a_replaced_conditioner():
     assert torch.equal(again["samples"], small["samples"]) and torch.equal(again["prob"], small["prob"])
     assert torch.equal(big["samples"], r.predict_batch(x, noise=nz4, use_graph=False)["samples"])
     print("conditioner handle address reused:", r.cond_pred_model._h.value == h_small)
+
+
+def test_probes_do_not_change_results_and_report_intervals():
+    """nd_set_profiling: event-record nodes inside the batch graph (bench.py's roofline probes) leave every output bit-identical;
+    nd_profile_read returns positive intervals for min(8, T - 1) probed steps, the empty interval being the smallest."""
+    K, T, B, mc, Cc = 5, 12, 4, 1, 2
+    r, (_, _, _, _, _, img) = _runner(K, T, B, mc)
+    g = torch.Generator().manual_seed(6)
+    x = torch.rand(B, 3, img, img, generator=g).cuda()
+    nz = torch.randn(K, T, B, Cc, generator=g).cuda()
+    plain = r.predict_batch(x, noise=nz)
+    r.engine.set_profiling(True)
+    for _ in range(2):                                            # eager + recording, then a replay
+        probed = r.predict_batch(x, noise=nz)
+    head, pair, rec, n = r.engine.profile_read()
+    r.engine.set_profiling(False)
+    assert n == 8 and head > 0 and pair > 0 and rec > 0 and rec < head and rec < pair
+    for k in ("samples", "prob", "vote", "probs", "yhat"):
+        assert torch.equal(plain[k], probed[k]), k
+    assert torch.equal(r.predict_batch(x, noise=nz)["samples"], plain["samples"])

@@ -33,6 +33,7 @@ for _ in range(reps):
     y = eng.sample(yhat, yhat, noise, mc=mc, T=T)
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / reps
-head, l2, l3, n = eng.profile_read()
+head, pair, rec, n = eng.profile_read()
 print(f"dtype={DT} K={K} T={T} B={B} mc={mc}: sampler {ms:.3f} ms = {ms*1e3/T:.1f} us/step; "
-      f"head {head:.1f} lin2 {l2:.1f} lin3 {l3:.1f} us ({n} probes); checksum {float(y.double().sum()):.9f}")
+      f"head {head - rec:.1f} us, step block {(pair - rec) / 2:.1f} us per launch (record node {rec:.1f} us subtracted; {n} probes); "
+      f"checksum {float(y.double().sum()):.9f}")
