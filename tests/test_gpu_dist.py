@@ -87,9 +87,12 @@ def _worker(rank, world, port, out_dir, backend):
     td.destroy_process_group()
 
 
-def test_two_ranks_sharded_batch_equals_full_batch(tmp_path):
-    world, port = 2, _free_port()
-    backend = "nccl" if torch.cuda.device_count() >= 2 else "gloo"
+@pytest.mark.parametrize("world", [2, 4])
+def test_ranks_sharded_batch_equals_full_batch(tmp_path, world):
+    """world = 2: shards of 4 + 3 images; world = 4: 2 + 2 + 2 + 1 (one rank per device over RCCL when the box has that many GPUs,
+    else the ranks share cuda:0 and gather over gloo; at most 5 GPU processes at once)."""
+    port = _free_port()
+    backend = "nccl" if torch.cuda.device_count() >= world else "gloo"
     mp.spawn(_worker, args=(world, port, str(tmp_path), backend), nprocs=world, join=True)
     for r in range(world):
         res = torch.load(os.path.join(str(tmp_path), f"r{r}.pt"))
