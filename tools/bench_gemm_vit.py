@@ -39,5 +39,15 @@ for name, K, N, act, res in shapes:
     err = float((y.double() - ref).abs().max() / ref.abs().max())
     if name != "patch_embed":
         tot += us
-    print(f"{name:12s} M={M} K={K:4d} N={N:4d}: {us:7.1f} us  {2 * M * K * N / us / 1e6:6.1f} TFLOP/s  rel err vs fp64 {err:.1e}", flush=True)
+    # library yardstick (not used by the product): the same product through torch.mm = rocBLAS / hipBLASLt sgemm, no epilogue
+    wt = w.t().contiguous()
+    for _ in range(3):
+        torch.mm(x, wt)
+    torch.cuda.synchronize(); e0.record()
+    for _ in range(reps):
+        torch.mm(x, wt)
+    e1.record(); torch.cuda.synchronize()
+    us_lib = e0.elapsed_time(e1) / reps * 1e3
+    print(f"{name:12s} M={M} K={K:4d} N={N:4d}: {us:7.1f} us  {2 * M * K * N / us / 1e6:6.1f} TFLOP/s  rel err vs fp64 {err:.1e}   "
+          f"[torch.mm fp32, bare product: {us_lib:7.1f} us {2 * M * K * N / us_lib / 1e6:6.1f} TFLOP/s]", flush=True)
 print(f"block GEMMs (qkv+proj+fc1+fc2): {tot:.1f} us")

@@ -27,7 +27,7 @@ for i in range(K):
 paths = []
 for i in range(K):
     p = os.path.join(a.dir, f"diffu{i}_ckpt_best.pth")
-    torch.save({"noise_estimator": cpu(synthetic.cond_model_state(D, H, F, C, T, seed=1000 + i)), "optimizer": {}, "epoch": 1}, p)
+    torch.save({"noise_estimator": cpu(synthetic.cond_model_state(D, H, F, C, T, seed=1000 + i, denoiser=T >= 500)), "optimizer": {}, "epoch": 1}, p)
     paths.append(p)
 print(f"checkpoints written in {time.time() - t0:.0f} s", flush=True)
 cfg = {"data": {"dataset": "ChestXRay", "seed": 4444, "num_classes": C, "num_workers": 0, "dataroot": "PATH"},
