@@ -160,3 +160,20 @@ def test_config4_isic_fp16_t1000_at_config_dims():
     top = s32.topk(2, dim=2).values                         # vote = argmax of raw y_0: equal away from near-ties
     safe = (top[..., 0] - top[..., 1]).amin(dim=0) > 10 * d_y0
     assert torch.equal(outs["f16"]["vote"][safe], outs["f32"]["vote"][safe])
+
+
+def test_bench_gpus2_under_torch_distributed_run():
+    """The driver's own launch form: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...` (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the launcher's environment)."""
+    torch.cuda.empty_cache()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    if torch.cuda.device_count() < 2:
+        env["ND_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["n_ranks_seen"] == 2 and line["cpu_baseline"] is None and line["value"] > 0
