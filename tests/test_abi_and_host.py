@@ -305,3 +305,46 @@ def test_step_gemm_loops_keep_counted_waits():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_waits.py")], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "0 degraded" in r.stdout
+
+
+def test_conditioner_and_batch_abi_argument_validation_without_gpu():
+    """Host-side checks of the round-3 entry points: configuration validation, workspace sizing and NULL handling return error
+    codes (with an nd_last_error text) before any HIP call."""
+    from nested_diffusion_amd import _lib
+    lib = _lib.load()
+
+    def cond_cfg(**over):
+        c = _lib.NdCondConfig()
+        c.img_size, c.patch, c.in_chans, c.embed_dim, c.num_heads, c.mlp_hidden, c.n_blocks, c.n_mlps = 224, 16, 3, 768, 12, 3072, 12, 5
+        c.mlp_widths[0], c.mlp_widths[1], c.mlp_widths[2] = 4096, 2048, 128
+        c.num_classes, c.max_batch, c.max_tokens, c.operand_dtype, c.ln_eps = 2, 32, 197, 0, 1e-6
+        for k, v in over.items():
+            setattr(c, k, v)
+        return c
+    good = cond_cfg()
+    nbytes = lib.nd_cond_workspace_bytes(ctypes.byref(good))
+    # activations of ViT-B/16 at B = 32: qkv [6304, 2304] + fc1 [6304, 3072] + five [6304, 768] + im2col + GEMM / linear workspaces
+    assert 250e6 < nbytes < 600e6, nbytes
+    h = ctypes.c_void_p()
+    assert lib.nd_cond_create(ctypes.byref(good), ctypes.byref(h)) == 0 and h.value
+    assert lib.nd_cond_get_config(h).contents.embed_dim == 768
+    assert lib.nd_cond_bind_workspace(h, None, nbytes) != 0 and b"NULL" in lib.nd_last_error()
+    assert lib.nd_cond_bind_workspace(h, 0x1001, nbytes) != 0 and b"aligned" in lib.nd_last_error()
+    assert lib.nd_cond_set_block(h, 12, ctypes.byref(_lib.NdVitBlockWeights())) != 0             # block index out of range
+    assert lib.nd_cond_set_block(h, 0, ctypes.byref(_lib.NdVitBlockWeights())) != 0 and b"NULL" in lib.nd_last_error()
+    assert lib.nd_guiding_prediction(h, 0x1000, 0x1000, None, 4, None) == -3                       # ND_ERR_STATE: workspace not bound
+    assert lib.nd_vit_block(h, 0, 0x1000, 0x1000, 4, 196, None) == -3
+    assert lib.nd_cond_destroy(h) == 0
+    for bad in (cond_cfg(embed_dim=760), cond_cfg(patch=15), cond_cfg(n_mlps=13), cond_cfg(max_tokens=100), cond_cfg(max_tokens=300),
+                cond_cfg(operand_dtype=3), cond_cfg(ln_eps=0.0), cond_cfg(max_batch=0)):
+        assert lib.nd_cond_workspace_bytes(ctypes.byref(bad)) == 0
+        assert lib.nd_cond_create(ctypes.byref(bad), ctypes.byref(ctypes.c_void_p())) != 0
+    mw = cond_cfg()
+    mw.mlp_widths[2] = 100                                                                           # not a multiple of 16
+    assert lib.nd_cond_workspace_bytes(ctypes.byref(mw)) == 0
+    assert lib.nd_philox_normal(None, 1, 1, 1, 1, 1, 0, 0, 0, None) != 0
+    assert lib.nd_philox_normal(0x1000, 0, 1, 1, 1, 1, 0, 0, 0, None) != 0
+    assert lib.nd_philox_raw(None, None, 1, 0, 0, None) != 0
+    assert lib.nd_predict_batch(None, None, None, None, None, 1, 1, 1, 0.5, 1, None) != 0
+    assert lib.nd_seed(None, 1, 0) != 0
+    assert lib.nd_resident_weight_bytes(None, 0) == -1
