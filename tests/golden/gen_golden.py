@@ -88,10 +88,10 @@ def make_config(D, H, Fd, C, T, dataset="ChestXRay"):
               data=ns(num_classes=C, dataset=dataset))
 
 
-def build_ref_model(lm, D, H, Fd, C, T, seed, denoiser=False):
+def build_ref_model(lm, D, H, Fd, C, T, seed, denoiser=False, guidance=True):
     cfg = make_config(D, H, Fd, C, T)
-    model = lm.ConditionalModel(cfg, guidance=True)
-    params = ref_cpu.init_cond_model_params(D, H, Fd, C, T, True, seed=seed, denoiser=denoiser)
+    model = lm.ConditionalModel(cfg, guidance=guidance)
+    params = ref_cpu.init_cond_model_params(D, H, Fd, C, T, guidance, seed=seed, denoiser=denoiser)
     missing = model.load_state_dict(params, strict=True)
     model.eval()
     return model, params
@@ -133,11 +133,12 @@ def gen_sampler_small(du, lm, only=None):
         ("s2", 96, 64, 80, 3, 25, 1, 13),        # C=3, B=1, F not a power of two
         ("s3", 160, 96, 256, 2, 1000, 5, 14),    # T=1000: 1/sqrt(abar) amplification (random weights: expansive chain)
         ("s4", 160, 96, 128, 2, 1000, 5, 15),    # T=1000 with the denoiser-structured init: contractive chain, |y_t| = O(1)
+        ("s5", 64, 48, 80, 3, 12, 4, 16),        # guidance=False (lin1 sees y alone, latent_model.py:157-158,172) + a per-row t vector
     ]
     for name, D, H, Fd, C, T, B, seed in cases:
         if only and name not in only:
             continue
-        model, params = build_ref_model(lm, D, H, Fd, C, T, seed, denoiser=(name == "s4"))
+        model, params = build_ref_model(lm, D, H, Fd, C, T, seed, denoiser=(name == "s4"), guidance=(name != "s5"))
         g = torch.Generator().manual_seed(seed + 100)
         x = torch.rand(B, D, generator=g)
         yhat = torch.softmax(torch.randn(B, C, generator=g), dim=1)
@@ -153,10 +154,12 @@ def gen_sampler_small(du, lm, only=None):
                 yy = seq[min(T - 1 - t, T - 1)]
                 eps[t] = model(x, yy, torch.tensor([t]), yhat)
             big = model(x * 40.0, seq[0] * 30.0, torch.tensor([T - 1]), yhat)   # drives softplus inputs > 20
+            t_rows = torch.tensor([(T - 1 - 3 * b) % T for b in range(B)])       # ConditionalModel.forward with t of shape [B]
+            eps_rows = model(x, seq[1], t_rows, yhat)
         save = {("p." + k): v.numpy() for k, v in params.items()}
         save.update(x=x.numpy(), yhat=yhat.numpy(), noise=noise.numpy(), seq=seq.numpy(),
                     alphas=alphas.numpy(), omabs=omabs.numpy(), eps_ts=np.array(ts),
-                    eps=np.stack([eps[t].numpy() for t in ts]), eps_big=big.numpy(),
+                    eps=np.stack([eps[t].numpy() for t in ts]), eps_big=big.numpy(), t_rows=t_rows.numpy(), eps_rows=eps_rows.numpy(),
                     dims=np.array([D, H, Fd, C, T, B, seed]))
         np.savez_compressed(os.path.join(OUT, f"sampler_{name}.npz"), **save)
         print(f"sampler_{name}.npz  y0[0]={seq[-1][0].tolist()}")

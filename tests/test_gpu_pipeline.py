@@ -77,6 +77,29 @@ def test_module_and_p_sample_loop_dropin():
         model.train()(x, yhat, torch.tensor([0]), yhat)        # inference only
 
 
+def test_guidance_false_model_vs_reference_golden():
+    """The nn.Module mirror built with guidance=False against golden s5 (the reference's own run of such a model): whole
+    p_sample_loop trajectory through the drop-in diffusion_utils.p_sample_loop, and a forward with a per-row t vector."""
+    import os
+    import numpy as np
+    from nested_diffusion_amd import diffusion_utils as du
+    from nested_diffusion_amd.latent_model import ConditionalModel
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "sampler_s5.npz"))
+    p = {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("p.")}
+    D, H, Fd, C, T, B, seed = [int(v) for v in z["dims"]]
+    model = ConditionalModel(small_config(D, H, Fd, C, T, B), guidance=False, max_batch=8)
+    model.load_state_dict(p)
+    model = model.cuda().eval()
+    x, yhat, noise = (torch.from_numpy(z[k]).cuda() for k in ("x", "yhat", "noise"))
+    alphas, omabs = torch.from_numpy(z["alphas"]).cuda(), torch.from_numpy(z["omabs"]).cuda()
+    seq = du.p_sample_loop(model, x, yhat, yhat, T, alphas, omabs, only_last_sample=False, noise=noise)
+    got = torch.stack(seq).cpu().numpy()
+    assert got.shape == z["seq"].shape
+    assert np.abs(got - z["seq"]).max() < 5e-5 * max(1.0, np.abs(z["seq"]).max())
+    e = model(x, torch.from_numpy(z["seq"][1]).cuda(), torch.from_numpy(z["t_rows"]).cuda(), yhat).cpu().numpy()
+    assert np.abs(e - z["eps_rows"]).max() < 5e-5 * max(1.0, np.abs(z["eps_rows"]).max())
+
+
 def test_guidance_false_and_per_row_timesteps():
     """The two call shapes of ConditionalModel.forward the inference loop never uses (latent_model.py:157-158: lin1 on y_t
     alone; :101-105: gamma = embed(t) with one t PER ROW, the training-time call) against the oracle, and a whole reverse
