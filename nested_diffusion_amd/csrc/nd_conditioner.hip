@@ -15,6 +15,9 @@
 #include "../../include/nested_diffusion.h"
 
 int nd_set_err(int code, const char* fmt, ...);
+// nd_ops.hip: Classifier.forward on packed activations (one input pack, hidden layers written in streaming order)
+int nd_mlp_chain(const float* x, const void* const* wpk, const float* const* bias, const int* dims, float* const* hid, float* logits,
+                 int M, int dtype, void* ws, size_t ws_bytes, void* stream);
 
 static std::atomic<unsigned long long> g_cond_serial{1};
 
@@ -76,7 +79,7 @@ static void carve(nd_cond_s* c, char* base, size_t* total) {
     c->qkv = (float*)take(R * 3 * E * 4);
     c->att = (float*)take(R * E * 4);
     c->fc1 = (float*)take(R * Hd * 4);
-    for (int i = 0; i < 3; ++i) c->m[i] = (float*)take(B * (size_t)g.mlp_widths[i] * 4);
+    for (int i = 0; i < 3; ++i) c->m[i] = (float*)take(((B + 15) / 16 * 16) * (size_t)g.mlp_widths[i] * 4);   // packed: whole 16-row tiles
     const int dt = g.operand_dtype;
     size_t gw = 0;
     const int rows[2] = {(int)(B * ntok), (int)R};
@@ -233,14 +236,8 @@ extern "C" int nd_guiding_prediction(nd_cond c, const float* images, float* logi
         ND_TRY(vit_block(c, i, c->tok, c->tok, B, ntok, stream));
         // mlps[i](tmp): reshape(-1, 196*768) -> 3 x (Linear, ReLU) -> Linear (mapping/models/mlp.py:23-29)
         const nd_mlp_weights& w = c->mlps[i];
-        const float* x = c->tok;
         float* logits = logits_out + (size_t)i * B * C;
-        for (int l = 0; l < 4; ++l) {
-            float* y = l < 3 ? c->m[l] : logits;
-            ND_TRY(nd_linear(x, w.w_packed[l], nullptr, w.bias[l], y, B, dims[l], dims[l + 1], l < 3 ? ND_ACT_RELU : ND_ACT_NONE, dt, c->lin_ws,
-                             c->lin_ws_bytes, stream));
-            x = y;
-        }
+        ND_TRY(nd_mlp_chain(c->tok, w.w_packed, w.bias, dims, c->m, logits, B, dt, c->lin_ws, c->lin_ws_bytes, stream));
         if (yhat_out) ND_TRY(nd_softmax_rows(logits, yhat_out + (size_t)i * B * C, B, C, stream));     // :755-758
     }
     return ND_OK;

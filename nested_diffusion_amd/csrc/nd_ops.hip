@@ -45,6 +45,28 @@ extern "C" size_t nd_linear_workspace_bytes(int M, int K, int N, int dtype) {
     return bytes + 256;
 }
 
+// One Linear on an ALREADY PACKED input: out = act(scale * (x . W^T) + shift); out_packed 0 row-major fp32, 1 frag16, 2 frag32h (the
+// layout the next streaming layer reads).  part: split-K partial sums / k-slab accumulators (nd_linear_workspace_bytes minus the
+// packed-x share).
+static int linear_packed(const float* xpk, const float* wf, const float* scale, const float* shift, float* out, int M, int K, int N, int act,
+                         int half, int out_packed, float* part, hipStream_t st) {
+    if (nd_use_splitk(K)) {
+        const SkinnyLaunch L = nd_skinny_launch<2>(K, N, M, 1, half);
+        SkinnyDesc sd{xpk, wf, nullptr, nullptr, nullptr, nullptr, part, K, N, 0, ND_ACT_NONE, 0};
+        HIP_CHECK(nd_launch_skinny(L, sd, nullptr, 1, M, 0, st));
+        SplitKEpiDesc se{part, scale, shift, out, N, L.S, act, out_packed};
+        const size_t q = (size_t)(((M + 15) / 16) * 16) * (((N + 15) / 16) * 16) / 4;
+        hipLaunchKernelGGL(k_splitk_epilogue, dim3((unsigned)((q + 255) / 256)), dim3(256), 0, st, se, (const SplitKEpiDesc*)nullptr, M, L.S);
+    } else {
+        SkinnyDesc d{xpk, wf, scale, shift, out, nullptr, nullptr, K, N, 0, act, out_packed};
+        const CondGemmPlan tp = nd_cond_gemm_plan(K, N, M, 1, half);
+        if (tp.use_tile) HIP_CHECK(nd_launch_cond_gemm(0, tp, d, nullptr, M, 0, part, st));      // more than 128 rows: LDS-tiled
+        else HIP_CHECK(nd_launch_skinny(nd_skinny_launch<0>(K, N, M, 1, half), d, nullptr, 1, M, 0, st));
+    }
+    HIP_CHECK(hipGetLastError());
+    return ND_OK;
+}
+
 extern "C" int nd_linear(const float* x, const void* wpk, const float* scale, const float* shift, float* out, int M, int K, int N,
                          int act, int dtype, void* ws, size_t ws_bytes, void* stream) {
     if (!x || !wpk || !out) return nd_set_err(ND_ERR_ARG, "NULL tensor");
@@ -55,26 +77,37 @@ extern "C" int nd_linear(const float* x, const void* wpk, const float* scale, co
     const size_t need = nd_linear_workspace_bytes(M, K, N, dtype);
     if (!ws || ws_bytes < need) return nd_set_err(ND_ERR_ARG, "workspace too small: %zu < %zu", ws_bytes, need);
     const int half = dtype == ND_DTYPE_F16;
-    hipStream_t st = (hipStream_t)stream;
     float* xpk = (float*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
     float* part = (float*)((char*)xpk + ((nd_packed_bytes_dt(M, K, half) + 255) & ~(size_t)255));
     int rc = nd_pack_rows(x, xpk, M, K, dtype, stream);
     if (rc != ND_OK) return rc;
-    const float* wf = (const float*)wpk;     // opaque 1 KiB operand blocks in either dtype
-    if (nd_use_splitk(K)) {
-        const SkinnyLaunch L = nd_skinny_launch<2>(K, N, M, 1, half);
-        SkinnyDesc sd{xpk, wf, nullptr, nullptr, nullptr, nullptr, part, K, N, 0, ND_ACT_NONE, 0};
-        HIP_CHECK(nd_launch_skinny(L, sd, nullptr, 1, M, 0, st));
-        SplitKEpiDesc se{part, scale, shift, out, N, L.S, act, 0};
-        const size_t q = (size_t)(((M + 15) / 16) * 16) * (((N + 15) / 16) * 16) / 4;
-        hipLaunchKernelGGL(k_splitk_epilogue, dim3((unsigned)((q + 255) / 256)), dim3(256), 0, st, se, (const SplitKEpiDesc*)nullptr, M, L.S);
-    } else {
-        SkinnyDesc d{xpk, wf, scale, shift, out, nullptr, nullptr, K, N, 0, act, 0};
-        const CondGemmPlan tp = nd_cond_gemm_plan(K, N, M, 1, half);
-        if (tp.use_tile) HIP_CHECK(nd_launch_cond_gemm(0, tp, d, nullptr, M, 0, part, st));      // more than 128 rows: LDS-tiled
-        else HIP_CHECK(nd_launch_skinny(nd_skinny_launch<0>(K, N, M, 1, half), d, nullptr, 1, M, 0, st));
+    return linear_packed(xpk, (const float*)wpk, scale, shift, out, M, K, N, act, half, 0, part, (hipStream_t)stream);
+}
+
+// mapping/models/mlp.py:23-29 as ONE sequence on packed activations (library-internal; nd_conditioner.hip): the input is packed
+// once, every hidden layer's epilogue writes its output in the fragment order the next layer streams (the same values nd_linear's
+// row-major output + re-pack would give, fp16 rounding included), the last layer writes row-major logits.
+//   dims[5] = {in, w1, w2, w3, classes}; hid[l]: >= 16*ceil(M/16) * dims[l+1] floats; ws: >= the largest nd_linear_workspace_bytes of
+//   the four layers.
+int nd_mlp_chain(const float* x, const void* const* wpk, const float* const* bias, const int* dims, float* const* hid, float* logits,
+                 int M, int dtype, void* ws, size_t ws_bytes, void* stream) {
+    const int half = dtype == ND_DTYPE_F16, opk = half ? 2 : 1;
+    for (int l = 0; l < 4; ++l)
+        if (ws_bytes < nd_linear_workspace_bytes(M, dims[l], dims[l + 1], dtype))
+            return nd_set_err(ND_ERR_ARG, "mlp chain workspace too small for layer %d", l + 1);
+    float* xpk = (float*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+    float* part = (float*)((char*)xpk + ((nd_packed_bytes_dt(M, dims[0], half) + 255) & ~(size_t)255));
+    int rc = nd_pack_rows(x, xpk, M, dims[0], dtype, stream);
+    if (rc != ND_OK) return rc;
+    const float* in = xpk;
+    for (int l = 0; l < 4; ++l) {
+        float* out = l < 3 ? hid[l] : logits;
+        // layers 2..4 read a packed activation of the previous epilogue; their split-K / k-slab scratch can start at the workspace base
+        rc = linear_packed(in, (const float*)wpk[l], nullptr, bias[l], out, M, dims[l], dims[l + 1], l < 3 ? ND_ACT_RELU : ND_ACT_NONE, half,
+                           l < 3 ? opk : 0, l == 0 ? part : xpk, (hipStream_t)stream);
+        if (rc != ND_OK) return rc;
+        in = out;
     }
-    HIP_CHECK(hipGetLastError());
     return ND_OK;
 }
 
