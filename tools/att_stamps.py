@@ -7,7 +7,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 csrc = os.path.join(ROOT, "nested_diffusion_amd", "csrc")
 lib = "/tmp/libnd_hip_stamps.so"
-srcs = ["nd_sampler.hip", "nd_ops.hip", "nd_vit.hip", "nd_image.hip", "nd_cond_gemm.hip", "nd_attention.hip", "nd_gemm_f32.hip"]
+srcs = ["nd_sampler.hip", "nd_ops.hip", "nd_vit.hip", "nd_image.hip", "nd_cond_gemm.hip", "nd_attention.hip", "nd_gemm_f32.hip",
+        "nd_conditioner.hip", "nd_rng.hip"]
 cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-shared", "-DND_ATT_STAMPS", "-mllvm", "-amdgpu-mfma-vgpr-form", "-o", lib] + [os.path.join(csrc, s) for s in srcs]
 subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
 os.environ["ND_LIB_PATH"] = lib            # read by nested_diffusion_amd._lib at import
