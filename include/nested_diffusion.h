@@ -49,7 +49,7 @@ typedef struct {
     int32_t hidden_dim;  /* H  = config.model.hidden_dim        (multiple of 16) */
     int32_t feature_dim; /* F  = config.model.feature_dim       (multiple of 16) */
     int32_t n_steps;     /* T  = config.diffusion.timesteps; embed tables hold T+1 rows */
-    int32_t n_members;   /* K  */
+    int32_t n_members;   /* K  (1..255) */
     int32_t max_batch;   /* largest B (images) per call */
     int32_t max_rows;    /* largest M = B * mc_trials per call */
     int32_t operand_dtype; /* ND_DTYPE_F32 (0): the reference's arithmetic.  ND_DTYPE_F16 (1): weights of the five large Linear

@@ -105,8 +105,9 @@ void* nd_rng_advance_kernel() { return (void*)k_rng_advance; }
 extern "C" int nd_philox_normal(float* out_dev, int n_members, int T, int B, int mc, int C, uint64_t seed, uint32_t batch_counter,
                                 uint32_t first_image, void* stream) {
     if (!out_dev) return nd_set_err(ND_ERR_ARG, "out_dev is NULL");
-    if (n_members < 1 || n_members > 65535 || T < 1 || B < 1 || mc < 1 || mc > 65535 || C < 1 || C > 1024)
-        return nd_set_err(ND_ERR_ARG, "need 1 <= n_members, mc <= 65535, T, B >= 1, 1 <= C <= 1024");
+    // counter word 1 = trial (16 bits) | member (8 bits) | class-quad (8 bits)
+    if (n_members < 1 || n_members > 255 || T < 1 || B < 1 || mc < 1 || mc > 65535 || C < 1 || C > 1024)
+        return nd_set_err(ND_ERR_ARG, "need 1 <= n_members <= 255, 1 <= mc <= 65535, T, B >= 1, 1 <= C <= 1024");
     HIP_CHECK(nd_launch_philox_normal(out_dev, nullptr, seed, batch_counter, first_image, n_members, T, B, mc, C, (hipStream_t)stream));
     return ND_OK;
 }

@@ -449,8 +449,8 @@ static int check_cfg(const nd_config* c) {
         return nd_set_err(ND_ERR_ARG, "operand_dtype must be ND_DTYPE_F32 or ND_DTYPE_F16");
     if (c->operand_dtype == ND_DTYPE_F16 && ((c->data_dim | c->hidden_dim | c->feature_dim) % 32))
         return nd_set_err(ND_ERR_ARG, "fp16 operands need data_dim, hidden_dim and feature_dim to be multiples of 32");
-    if (c->n_members < 1 || c->max_batch < 1 || c->max_rows < c->max_batch)
-        return nd_set_err(ND_ERR_ARG, "n_members/max_batch/max_rows invalid");
+    if (c->n_members < 1 || c->n_members > 255 || c->max_batch < 1 || c->max_rows < c->max_batch)
+        return nd_set_err(ND_ERR_ARG, "n_members (1..255) / max_batch / max_rows invalid");
     return ND_OK;
 }
 
@@ -724,7 +724,8 @@ extern "C" int nd_profile_read(nd_handle h, float* out_us, int* n_samples) {
 
 static int check_rows(nd_handle_s* h, int B, int mc, int T) {
     if (B < 1 || B > h->cfg.max_batch) return nd_set_err(ND_ERR_ARG, "B=%d outside [1,%d]", B, h->cfg.max_batch);
-    if (mc < 1 || (long)B * mc > h->cfg.max_rows) return nd_set_err(ND_ERR_ARG, "B*mc=%ld exceeds max_rows=%d", (long)B * mc, h->cfg.max_rows);
+    if (mc < 1 || mc > 65535 || (long)B * mc > h->cfg.max_rows)
+        return nd_set_err(ND_ERR_ARG, "mc=%d outside [1,65535] or B*mc=%ld exceeds max_rows=%d", mc, (long)B * mc, h->cfg.max_rows);
     if (T < 1 || T > h->cfg.n_steps) return nd_set_err(ND_ERR_ARG, "T=%d outside [1,%d]", T, h->cfg.n_steps);
     if (h->sched_T < T) return nd_set_err(ND_ERR_STATE, "schedule holds %d steps, need %d (nd_set_schedule)", h->sched_T, T);
     if (h->encoded_B != B) return nd_set_err(ND_ERR_STATE, "nd_encode ran with B=%d, sampling asks B=%d", h->encoded_B, B);
@@ -992,7 +993,8 @@ extern "C" int nd_predict_batch(nd_handle h, nd_cond c, const float* images_dev,
     int rc = check_range(h, 0, g.n_members);
     if (rc != ND_OK) return rc;
     if (B < 1 || B > g.max_batch || B > cc->max_batch) return nd_set_err(ND_ERR_ARG, "B=%d outside [1,%d]", B, g.max_batch < cc->max_batch ? g.max_batch : cc->max_batch);
-    if (mc < 1 || (long)B * mc > g.max_rows) return nd_set_err(ND_ERR_ARG, "B*mc=%ld exceeds max_rows=%d", (long)B * mc, g.max_rows);
+    if (mc < 1 || mc > 65535 || (long)B * mc > g.max_rows)
+        return nd_set_err(ND_ERR_ARG, "mc=%d outside [1,65535] or B*mc=%ld exceeds max_rows=%d", mc, (long)B * mc, g.max_rows);
     if (T < 1 || T > g.n_steps) return nd_set_err(ND_ERR_ARG, "T=%d outside [1,%d]", T, g.n_steps);
     if (h->sched_T < T) return nd_set_err(ND_ERR_STATE, "schedule holds %d steps, need %d (nd_set_schedule)", h->sched_T, T);
     if (!(temperature > 0.f)) return nd_set_err(ND_ERR_ARG, "temperature must be > 0");
