@@ -174,7 +174,7 @@ def launch_ranks(n: int, argv) -> int:
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))      # HSA_ENABLE_IPC_MODE_LEGACY: nested_diffusion_amd/dist.py
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env))
     rc = 0
     live = list(procs)
@@ -211,10 +211,14 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     from nested_diffusion_amd import dist as nd_dist
-    rank, local, world = nd_dist.init_from_env()
+    # ND_FORCE_DIST=1: run the N > 1 branches below (process-group init on the production backend, barriers, the device all-reduce of
+    # the step time, the batch's all-gather) in a ONE-rank group -- what a 1-GPU box can rehearse of the RCCL call sequence
+    force_dist = os.environ.get("ND_FORCE_DIST", "0") == "1"
+    rank, local, world = nd_dist.init_from_env(force=force_dist)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    n_ranks_seen = torch.distributed.get_world_size() if world > 1 else 1
+    dist_on = world > 1 or force_dist
+    n_ranks_seen = torch.distributed.get_world_size() if dist_on else 1
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local)
@@ -235,24 +239,31 @@ def main():
     def step(noise=None):
         # ONE library call = one hipGraph launch: conditioner, encoder hoist, K*T reverse steps (noise drawn in-library), aggregation
         out = runner.predict_batch(images, noise=noise, clone=False)
-        if world > 1:
-            out["prob_all"] = nd_dist.all_gather_rows(out["prob"], B * world, world)   # the single collective
+        if dist_on:
+            out["prob_all"] = nd_dist.all_gather_rows(out["prob"], B * world, world, force_collective=force_dist)   # the single collective
         return out
+
+    def barrier():
+        # RCCL: name the device, or the first barrier of a group guesses it from the rank (and warns)
+        if torch.distributed.get_backend() == "nccl":
+            torch.distributed.barrier(device_ids=[local])
+        else:
+            torch.distributed.barrier()
 
     def timed_steps(n):
         torch.cuda.synchronize(device)
-        if world > 1:
-            torch.distributed.barrier()
+        if dist_on:
+            barrier()
             torch.cuda.synchronize(device)
         t0 = time.perf_counter()
         for _ in range(n):
             out = step()
         torch.cuda.synchronize(device)
-        if world > 1:
-            torch.distributed.barrier()
+        if dist_on:
+            barrier()
             torch.cuda.synchronize(device)
         dt = time.perf_counter() - t0
-        if world > 1:
+        if dist_on:
             tmax = torch.tensor([dt], dtype=torch.float64, device=device if torch.distributed.get_backend() == "nccl" else "cpu")
             torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
             dt = float(tmax.item())
@@ -267,7 +278,9 @@ def main():
     dt, out = timed_steps(args.steps)
     head_us, pair_us, rec_us, n_probe = eng.profile_read()
     eng.set_profiling(False)
-    step()
+    chk = step()
+    # the gathered tensor holds this rank's rows where they belong (out["prob"] is a fixed buffer: compared before the next step)
+    collective_checked = bool(torch.equal(chk["prob_all"][rank * B:(rank + 1) * B], chk["prob"])) if dist_on else None
     dt_unprobed, _ = timed_steps(args.steps)
 
     # the same loop with the batch handed over as a HOST buffer (pinned, as a DataLoader with pin_memory delivers it): the H2D copy
@@ -305,7 +318,7 @@ def main():
     }
 
     if rank != 0:
-        if world > 1:
+        if dist_on:
             torch.distributed.destroy_process_group()
         return
     units = B * K * mc * T
@@ -371,7 +384,9 @@ def main():
     line = {
         "metric": "denoising-steps*images/sec (K=5,T=100,224^2)", "value": value, "unit": "denoising-step*images/s",
         "n_gpus": world, "n_ranks_seen": n_ranks_seen,
-        "dist_backend": torch.distributed.get_backend() if world > 1 else None, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+        "dist_backend": torch.distributed.get_backend() if dist_on else None,
+        "collective_checked": collective_checked,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32" if args.dtype == "f32" else "f16 operands / f32 accumulate (secondary mode, not the reference's arithmetic)",
         "data": "synthetic",
@@ -399,7 +414,7 @@ def main():
     else:
         line["cpu_baseline"] = None
     print(json.dumps(line))
-    if world > 1:
+    if dist_on:
         torch.distributed.destroy_process_group()
 
 

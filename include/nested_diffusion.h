@@ -44,7 +44,8 @@ typedef struct nd_handle_s *nd_handle;
  * guidance=True) that share shapes.  Config dims: y_dim 2, data_dim 150528, hidden 4096,
  * feature 4096 (configs/chest_x_ray.yml:5,11,14-15). */
 typedef struct {
-    int32_t y_dim;       /* C  = config.data.num_classes */
+    int32_t y_dim;       /* C  = config.data.num_classes (1..8: a library limit the reference does not have -- the step head keeps a
+                          *     row's C state values and C eps sums in registers; the shipped configs use 2) */
     int32_t data_dim;    /* D  = config.model.data_dim          (multiple of 16) */
     int32_t hidden_dim;  /* H  = config.model.hidden_dim        (multiple of 16) */
     int32_t feature_dim; /* F  = config.model.feature_dim       (multiple of 16) */
@@ -144,6 +145,10 @@ int nd_set_profiling(nd_handle h, int enable);
  * roofline report separate bytes DELIVERED to the CUs from bytes that come out of DRAM.  -1 on a bad argument. */
 long long nd_resident_weight_bytes(nd_handle h, int block);
 int nd_profile_read(nd_handle h, float *out_us, int *n_samples);
+/* Number of hipGraph event-record nodes in the most recently BUILT nd_sample / nd_predict_batch graph (4 per probed step when
+ * profiling is on, 0 when it is off; -1 if the graph could not be walked): what a test checks to know that nd_profile_read's
+ * intervals are stamped on every replay and are not left over from the eager first call. */
+int nd_profile_probe_nodes(nd_handle h);
 
 /* Copy of an internal per-member activation (tests / debugging), converted from the packed layout to
  * row-major: which = 0 xe [rows<=B, F], 1 h1 [rows<=M, F], 2 h2 [rows<=M, F] -> dst_dev [rows, F]. */
@@ -293,7 +298,9 @@ int nd_guiding_prediction(nd_cond c, const float *images_dev, float *logits_out_
  *   noise_dev  [K, T, mc*B, C] in the reference's draw order, or NULL for in-library Philox noise (nd_seed)
  *   out->samples [K*mc, B, C] raw y_0, member-major then trial (the order of mc_samples, :767-784)
  *   out->prob [B, C], out->vote [B] int64, out->probs [K*mc, B, C] (optional), out->yhat [K, B, C]
- * The ensemble handle must hold exactly cfg.n_mlps loaded members (member k is conditioned on mapping MLP k). */
+ * K = the ensemble handle's n_members, all loaded, K <= the conditioner's n_mlps: member k is conditioned on mapping MLP k, and only
+ * the first K mapping MLPs (and the prefix blocks they need) are evaluated -- the reference samples selected_block_indices ∩ the
+ * available diffusion checkpoints (:275, :769), e.g. 3 noise estimators beside 5 mapping MLPs. */
 typedef struct { float *samples; float *prob; int64_t *vote; float *probs; float *yhat; } nd_batch_out;
 int nd_predict_batch(nd_handle h, nd_cond c, const float *images_dev, const float *noise_dev, const nd_batch_out *out,
                      int B, int mc, int T, float temperature, int use_graph, void *stream);

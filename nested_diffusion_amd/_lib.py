@@ -103,6 +103,7 @@ SIGNATURES = {
     "nd_sample": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "nd_set_profiling": (_i, [_vp, _i]),
     "nd_profile_read": (_i, [_vp, C.POINTER(C.c_float), C.POINTER(_i)]),
+    "nd_profile_probe_nodes": (_i, [_vp]),
     "nd_resident_weight_bytes": (C.c_longlong, [_vp, _i]),
     "nd_member_buffer": (_i, [_vp, _i, _i, _vp, _i, _vp]),
     "nd_seed": (_i, [_vp, C.c_uint64, C.c_uint32]),

@@ -136,9 +136,16 @@ extern "C" int nd_cond_destroy(nd_cond c) {
 extern "C" int nd_cond_bind_workspace(nd_cond c, void* ws, size_t bytes) {
     if (!c || !ws) return nd_set_err(ND_ERR_ARG, "conditioner / workspace is NULL");
     if ((uintptr_t)ws & 255) return nd_set_err(ND_ERR_ARG, "workspace must be 256-byte aligned");
+    // size first, on a scratch copy: a rejected buffer must leave the handle's activation pointers (and the graphs recorded under
+    // its serial) exactly as they were
     size_t need = 0;
-    carve(c, (char*)ws, &need);
+    {
+        nd_cond_s tmp;
+        tmp.cfg = c->cfg;
+        carve(&tmp, nullptr, &need);
+    }
     if (bytes < need) return nd_set_err(ND_ERR_ARG, "workspace too small: %zu < %zu", bytes, need);
+    carve(c, (char*)ws, &need);
     c->ws = (char*)ws;
     c->ws_bytes = bytes;
     touch(c);
@@ -216,13 +223,17 @@ extern "C" int nd_vit_block(nd_cond c, int block, const float* tok_in, float* to
     return vit_block(c, block, tok_in, tok_out, B, N, stream);
 }
 
-extern "C" int nd_guiding_prediction(nd_cond c, const float* images, float* logits_out, float* yhat_out, int B, void* stream) {
+// The first n_used of the conditioner's mapping MLPs (and the prefix blocks they need): nd_predict_batch with an ensemble of
+// fewer noise estimators than mapping MLPs (the reference samples `selected_block_indices` ∩ available checkpoints,
+// classification_train_separately.py:275, 769) computes only the conditions it samples from.
+int nd_guiding_prediction_first(nd_cond c, const float* images, float* logits_out, float* yhat_out, int B, int n_used, void* stream) {
     if (!c || !c->ws) return nd_set_err(ND_ERR_STATE, "conditioner workspace not bound");
     if (!images || !logits_out) return nd_set_err(ND_ERR_ARG, "NULL tensor");
     const nd_cond_config& g = c->cfg;
     if (B < 1 || B > g.max_batch) return nd_set_err(ND_ERR_ARG, "B=%d outside [1,%d]", B, g.max_batch);
+    if (n_used < 1 || n_used > g.n_mlps) return nd_set_err(ND_ERR_ARG, "n_used=%d outside [1,%d]", n_used, g.n_mlps);
     if (!c->have_pe) return nd_set_err(ND_ERR_STATE, "patch embedding not set");
-    for (int i = 0; i < g.n_mlps; ++i)
+    for (int i = 0; i < n_used; ++i)
         if (!c->have_block[i] || !c->have_mlp[i]) return nd_set_err(ND_ERR_STATE, "block / mlp %d not set", i);
     const int E = g.embed_dim, gs = g.img_size / g.patch, ntok = gs * gs, kpe = g.in_chans * g.patch * g.patch, dt = g.operand_dtype;
     const int C = g.num_classes;
@@ -231,7 +242,7 @@ extern "C" int nd_guiding_prediction(nd_cond c, const float* images, float* logi
     ND_TRY(nd_gemm_bias_act(c->cols, c->pe.proj_w, c->pe.proj_b, nullptr, c->tok, B * ntok, kpe, E, ND_ACT_NONE, dt, c->gemm_ws,
                             c->gemm_ws_bytes, stream));
     const int dims[5] = {ntok * E, g.mlp_widths[0], g.mlp_widths[1], g.mlp_widths[2], C};
-    for (int i = 0; i < g.n_mlps; ++i) {
+    for (int i = 0; i < n_used; ++i) {
         // member i's prefix blocks[0..i] reuse member i-1's tokens (:339-340 recomputes them from patch_embed: same values)
         ND_TRY(vit_block(c, i, c->tok, c->tok, B, ntok, stream));
         // mlps[i](tmp): reshape(-1, 196*768) -> 3 x (Linear, ReLU) -> Linear (mapping/models/mlp.py:23-29)
@@ -241,4 +252,9 @@ extern "C" int nd_guiding_prediction(nd_cond c, const float* images, float* logi
         if (yhat_out) ND_TRY(nd_softmax_rows(logits, yhat_out + (size_t)i * B * C, B, C, stream));     // :755-758
     }
     return ND_OK;
+}
+
+extern "C" int nd_guiding_prediction(nd_cond c, const float* images, float* logits_out, float* yhat_out, int B, void* stream) {
+    if (!c) return nd_set_err(ND_ERR_STATE, "conditioner workspace not bound");
+    return nd_guiding_prediction_first(c, images, logits_out, yhat_out, B, c->cfg.n_mlps, stream);
 }

@@ -46,7 +46,7 @@ __device__ __forceinline__ void nd_box_muller(uint32_t a, uint32_t b, float& z0,
 // `state` is non-null (so a replayed hipGraph sees the current values), else taken from the arguments.
 __global__ __launch_bounds__(256) void k_philox_normal(float* __restrict__ out, const unsigned long long* __restrict__ state,
                                                        unsigned long long seed_arg, uint32_t batch_arg, uint32_t first_arg,
-                                                       int nm, int T, int B, int mc, int C) {
+                                                       int m0, int nm, int T, int B, int mc, int C) {
     const int Q = (C + 3) / 4, M = B * mc;
     const size_t total = (size_t)nm * T * M * Q;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -63,7 +63,9 @@ __global__ __launch_bounds__(256) void k_philox_normal(float* __restrict__ out, 
     const int i = (int)((idx / ((size_t)Q * M)) % T);
     const int k = (int)(idx / ((size_t)Q * M * T));
     const int trial = m / B, b = m % B;
-    uint32_t c[4] = {first + (uint32_t)b, (uint32_t)trial | ((uint32_t)k << 16) | ((uint32_t)q << 24), (uint32_t)i, batch};
+    // member index = its position in the ENSEMBLE (m0 + k), not in this call's range: a member's draws do not depend on how the
+    // members are split over calls
+    uint32_t c[4] = {first + (uint32_t)b, (uint32_t)trial | ((uint32_t)(m0 + k) << 16) | ((uint32_t)q << 24), (uint32_t)i, batch};
     nd_philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
     float z[4];
     nd_box_muller(c[0], c[1], z[0], z[1]);
@@ -88,9 +90,9 @@ __global__ void k_philox_raw(const uint32_t* __restrict__ ctr, uint32_t* __restr
 }
 
 hipError_t nd_launch_philox_normal(float* out, const unsigned long long* state_dev, unsigned long long seed, uint32_t batch, uint32_t first,
-                                   int nm, int T, int B, int mc, int C, hipStream_t st) {
+                                   int m0, int nm, int T, int B, int mc, int C, hipStream_t st) {
     const size_t total = (size_t)nm * T * B * mc * ((C + 3) / 4);
-    hipLaunchKernelGGL(k_philox_normal, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, out, state_dev, seed, batch, first, nm, T, B, mc, C);
+    hipLaunchKernelGGL(k_philox_normal, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, out, state_dev, seed, batch, first, m0, nm, T, B, mc, C);
     return hipGetLastError();
 }
 
@@ -108,7 +110,7 @@ extern "C" int nd_philox_normal(float* out_dev, int n_members, int T, int B, int
     // counter word 1 = trial (16 bits) | member (8 bits) | class-quad (8 bits)
     if (n_members < 1 || n_members > 255 || T < 1 || B < 1 || mc < 1 || mc > 65535 || C < 1 || C > 1024)
         return nd_set_err(ND_ERR_ARG, "need 1 <= n_members <= 255, 1 <= mc <= 65535, T, B >= 1, 1 <= C <= 1024");
-    HIP_CHECK(nd_launch_philox_normal(out_dev, nullptr, seed, batch_counter, first_image, n_members, T, B, mc, C, (hipStream_t)stream));
+    HIP_CHECK(nd_launch_philox_normal(out_dev, nullptr, seed, batch_counter, first_image, 0, n_members, T, B, mc, C, (hipStream_t)stream));
     return ND_OK;
 }
 

@@ -340,6 +340,7 @@ struct GraphKey {
     }
 };
 
+int nd_guiding_prediction_first(nd_cond c, const float* images, float* logits_out, float* yhat_out, int B, int n_used, void* stream);
 unsigned long long nd_cond_serial(nd_cond c);     // nd_conditioner.hip: changes with every change of the conditioner's state
 
 struct BatchKey {
@@ -382,6 +383,7 @@ struct nd_handle_s {
     bool profiling = false;
     std::vector<hipEvent_t> probe_events;   // 4 per probed step: e0 | head | e1 | lin2, lin3 | e2 | (nothing) | e3
     int probe_steps = 0;
+    int probe_nodes = 0;             // event-record nodes in the most recently built graph (nd_profile_probe_nodes)
 };
 
 static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -704,6 +706,26 @@ extern "C" int nd_set_profiling(nd_handle h, int enable) {
     return ND_OK;
 }
 
+// event-record nodes of a graph about to be instantiated (-1 if the graph cannot be walked)
+static int count_event_record_nodes(hipGraph_t g) {
+    size_t n = 0;
+    if (hipGraphGetNodes(g, nullptr, &n) != hipSuccess) return -1;
+    std::vector<hipGraphNode_t> nodes(n);
+    if (n && hipGraphGetNodes(g, nodes.data(), &n) != hipSuccess) return -1;
+    int cnt = 0;
+    for (size_t i = 0; i < n; ++i) {
+        hipGraphNodeType ty;
+        if (hipGraphNodeGetType(nodes[i], &ty) != hipSuccess) return -1;
+        if (ty == hipGraphNodeTypeEventRecord) ++cnt;
+    }
+    return cnt;
+}
+
+extern "C" int nd_profile_probe_nodes(nd_handle h) {
+    if (!h) return nd_set_err(ND_ERR_ARG, "handle is NULL");
+    return h->probe_nodes;
+}
+
 extern "C" int nd_profile_read(nd_handle h, float* out_us, int* n_samples) {
     if (!h || !out_us || !n_samples) return nd_set_err(ND_ERR_ARG, "NULL argument");
     double acc[3] = {0, 0, 0};
@@ -790,9 +812,27 @@ struct Emitter {
     hipGraph_t graph = nullptr;
     hipGraphNode_t last = nullptr;
     hipError_t err = hipSuccess;
+    bool capturing = false;          // st is being captured into a graph (nd_predict_batch)
     void record(hipEvent_t ev) {
         if (err != hipSuccess) return;
-        if (!graph) {
+        if (!graph && capturing) {
+            // Under stream capture a plain hipEventRecord only orders the captured work: nothing would stamp the event when the
+            // graph is replayed.  Put an event-record NODE into the graph being captured, behind the stream's current dependency
+            // set, and make it the stream's new dependency set (hipEventRecordWithFlags(..., hipEventRecordExternal) is the short
+            // form of this, but returns hipErrorInvalidValue under relaxed-mode capture on ROCm 7.2).
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            unsigned long long id = 0;
+            hipGraph_t g = nullptr;
+            const hipGraphNode_t* deps = nullptr;
+            size_t ndeps = 0;
+            err = hipStreamGetCaptureInfo_v2(st, &cs, &id, &g, &deps, &ndeps);
+            if (err != hipSuccess) return;
+            if (cs != hipStreamCaptureStatusActive || !g) { err = hipErrorStreamCaptureInvalidated; return; }
+            hipGraphNode_t node;
+            err = hipGraphAddEventRecordNode(&node, g, deps, ndeps, ev);
+            if (err != hipSuccess) return;
+            err = hipStreamUpdateCaptureDependencies(st, &node, 1, hipStreamSetCaptureDependencies);
+        } else if (!graph) {
             err = hipEventRecord(ev, st);
         } else {
             hipGraphNode_t node;
@@ -884,8 +924,11 @@ static hipError_t emit_loop(nd_handle_s* h, Emitter& em, int m0, int nm, StepIO 
 
 // Enqueue (eager, or under stream capture) the kernels of one sampling call: [Philox fill] -> 3T+1 step kernels -> [advance].
 static int run_loop_eager(nd_handle_s* h, hipStream_t st, int m0, int nm, StepIO io, bool draw, int B, int mc, int T) {
-    if (draw) HIP_CHECK(nd_launch_philox_normal(h->noise_ws, h->rng_state, 0, 0, 0, nm, T, B, mc, h->cfg.y_dim, st));
+    if (draw) HIP_CHECK(nd_launch_philox_normal(h->noise_ws, h->rng_state, 0, 0, 0, m0, nm, T, B, mc, h->cfg.y_dim, st));
     Emitter em{st};
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    HIP_CHECK(hipStreamIsCapturing(st, &cs));
+    em.capturing = cs == hipStreamCaptureStatusActive;
     hipError_t e = emit_loop(h, em, m0, nm, io, B, mc, T);
     if (e != hipSuccess) return nd_set_err(ND_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
     if (draw) HIP_CHECK(nd_launch_rng_advance(h->rng_state, st));
@@ -922,8 +965,8 @@ extern "C" int nd_sample(nd_handle h, int m0, int nm, const float* yhat_dev, con
             const unsigned long long* state = h->rng_state;
             unsigned long long seed0 = 0;
             uint32_t z0 = 0, z1 = 0;
-            int nmv = nm, Tv = T, Bv = B, mcv = mc, Cv = C;
-            void* a[] = {&out, &state, &seed0, &z0, &z1, &nmv, &Tv, &Bv, &mcv, &Cv};
+            int m0v = m0, nmv = nm, Tv = T, Bv = B, mcv = mc, Cv = C;
+            void* a[] = {&out, &state, &seed0, &z0, &z1, &m0v, &nmv, &Tv, &Bv, &mcv, &Cv};
             const size_t total = (size_t)nm * T * M * ((C + 3) / 4);
             em.emit(nd_philox_normal_kernel(), dim3((unsigned)((total + 255) / 256)), dim3(256), a);
         }
@@ -938,6 +981,7 @@ extern "C" int nd_sample(nd_handle h, int m0, int nm, const float* yhat_dev, con
             (void)hipGraphDestroy(em.graph);
             return nd_set_err(ND_ERR_HIP, "graph build failed: %s", hipGetErrorString(e));
         }
+        h->probe_nodes = count_event_record_nodes(em.graph);
         hipGraphExec_t exec;
         e = hipGraphInstantiate(&exec, em.graph, nullptr, nullptr, 0);
         (void)hipGraphDestroy(em.graph);
@@ -964,7 +1008,7 @@ static int batch_enqueue(nd_handle_s* h, nd_cond c, const float* images, const f
                          int T, float temperature, hipStream_t st) {
     const int K = h->cfg.n_members, C = h->cfg.y_dim, M = B * mc;
     const bool draw = noise == nullptr;
-    int rc = nd_guiding_prediction(c, images, h->logits_ws, out->yhat, B, st);
+    int rc = nd_guiding_prediction_first(c, images, h->logits_ws, out->yhat, B, K, st);     // member k <- mapping MLP k, k < K
     if (rc != ND_OK) return rc;
     rc = nd_encode(h, 0, K, images, B, st);
     if (rc != ND_OK) return rc;
@@ -986,7 +1030,7 @@ extern "C" int nd_predict_batch(nd_handle h, nd_cond c, const float* images_dev,
     if (!images_dev || !out || !out->samples || !out->prob || !out->vote || !out->yhat) return nd_set_err(ND_ERR_ARG, "NULL tensor");
     const nd_cond_config* cc = nd_cond_get_config(c);
     const nd_config& g = h->cfg;
-    if (cc->n_mlps != g.n_members) return nd_set_err(ND_ERR_ARG, "conditioner has %d mapping MLPs, ensemble %d members", cc->n_mlps, g.n_members);
+    if (cc->n_mlps < g.n_members) return nd_set_err(ND_ERR_ARG, "conditioner has %d mapping MLPs, ensemble %d members", cc->n_mlps, g.n_members);
     if (cc->num_classes != g.y_dim) return nd_set_err(ND_ERR_ARG, "conditioner has %d classes, ensemble %d", cc->num_classes, g.y_dim);
     if ((long)cc->in_chans * cc->img_size * cc->img_size != g.data_dim)
         return nd_set_err(ND_ERR_ARG, "image size %dx%dx%d != data_dim %d", cc->in_chans, cc->img_size, cc->img_size, g.data_dim);
@@ -1019,6 +1063,7 @@ extern "C" int nd_predict_batch(nd_handle h, nd_cond c, const float* images_dev,
             return rc;
         }
         if (e != hipSuccess) return nd_set_err(ND_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
+        h->probe_nodes = count_event_record_nodes(graph);
         hipGraphExec_t exec;
         e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
         (void)hipGraphDestroy(graph);

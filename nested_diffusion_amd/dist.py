@@ -13,8 +13,31 @@ from typing import Tuple
 import torch
 import torch.distributed as td
 
+# The hosts of this pool support only dmabuf IPC: with the legacy IPC mode RCCL's (and torch's) cross-process device-memory handles
+# fail with `hipIpcGetMemHandle: invalid argument`.  The variable is read when the HSA runtime starts, so it has to be in the
+# environment BEFORE the first GPU call of every rank -- whichever launcher started it (bench.py's own children, the tests'
+# children, torch.distributed.run): set here, at import, and again at the top of init_from_env; an explicit setting wins.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+
+# Single-process rehearsal of an N-rank run (tests only; see emulate_rank): (rank, world, sink)
+_EMULATED = None
+
+
+def emulate_rank(rank: int = None, world: int = None, sink: dict = None) -> None:
+    """Rehearse rank `rank` of a `world`-rank job inside ONE process, with no process group: rank_world() reports (rank, world) and
+    all_gather_rows() deposits this rank's padded shard in sink[rank] and assembles whatever shards the sink holds so far (rows of
+    ranks that have not run yet are zero).  Running ranks 0 .. world-1 one after the other therefore leaves, after the last one,
+    exactly the tensor the real all-gather returns on every rank.  This exists because a GPU box admits at most 6 processes on its
+    card: BASELINE configs[3]'s real shape (8 ranks x 32 rows) cannot be rehearsed there as 8 processes sharing the device.
+    emulate_rank() with no arguments switches it off."""
+    global _EMULATED
+    _EMULATED = None if rank is None else (int(rank), int(world), sink if sink is not None else {})
+
 
 def rank_world() -> Tuple[int, int]:
+    if _EMULATED is not None:
+        return _EMULATED[0], _EMULATED[1]
     if td.is_available() and td.is_initialized():
         return td.get_rank(), td.get_world_size()
     return 0, 1
@@ -24,6 +47,7 @@ def init_from_env(backend: str = None, force: bool = False) -> Tuple[int, int, i
     """Initialise from torchrun's env (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).  Returns
     (rank, local_rank, world).  No-op for single-process runs unless `force` (a one-rank group: lets a 1-GPU box run the
     RCCL initialisation and collective of the production branch)."""
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # before any GPU call (see the note at the top of this file)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -78,13 +102,21 @@ def all_gather_rows(local: torch.Tensor, n_total: int, world: int = None, force_
     q, r = divmod(n_total, world)
     widest = q + (1 if r else 0)
     dev = local.device
-    # RCCL gathers device tensors directly; gloo (CPU rehearsal of the N>1 path) is staged through the host
-    stage = torch.device("cpu") if (td.get_backend() == "gloo" and local.is_cuda) else dev
-    pad = torch.zeros((widest,) + tuple(local.shape[1:]), dtype=local.dtype, device=stage)
-    pad[: local.shape[0]] = local.to(stage)
-    out = torch.empty((world * widest,) + tuple(local.shape[1:]), dtype=local.dtype, device=stage)
-    td.all_gather_into_tensor(out, pad)
-    out = out.to(dev)
+    if _EMULATED is not None:
+        # rehearsal (emulate_rank): same padding and the same unpadding below, the collective replaced by the sink
+        sink = _EMULATED[2]
+        pad = torch.zeros((widest,) + tuple(local.shape[1:]), dtype=local.dtype, device=dev)
+        pad[: local.shape[0]] = local
+        sink[rank] = pad
+        out = torch.cat([sink[k].to(dev) if k in sink else torch.zeros_like(pad) for k in range(world)], dim=0)
+    else:
+        # RCCL gathers device tensors directly; gloo (CPU rehearsal of the N>1 path) is staged through the host
+        stage = torch.device("cpu") if (td.get_backend() == "gloo" and local.is_cuda) else dev
+        pad = torch.zeros((widest,) + tuple(local.shape[1:]), dtype=local.dtype, device=stage)
+        pad[: local.shape[0]] = local.to(stage)
+        out = torch.empty((world * widest,) + tuple(local.shape[1:]), dtype=local.dtype, device=stage)
+        td.all_gather_into_tensor(out, pad)
+        out = out.to(dev)
     if r == 0:
         return out
     pieces = []

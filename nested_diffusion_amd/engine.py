@@ -162,6 +162,10 @@ class EnsembleEngine:
         self.probe_overhead_us = float(us[3])
         return float(us[0]), float(us[1]), float(us[3]), int(n.value)
 
+    def probe_nodes(self) -> int:
+        """Event-record nodes in the most recently built sampling / batch graph (4 per probed step with profiling on, else 0)."""
+        return int(self.lib.nd_profile_probe_nodes(self.h))
+
     def resident_weight_bytes(self) -> Tuple[int, int]:
         """(lin2, lin3) weight bytes per step launch that are kept Infinity-Cache resident across steps."""
         a, b = self.lib.nd_resident_weight_bytes(self.h, 0), self.lib.nd_resident_weight_bytes(self.h, 1)

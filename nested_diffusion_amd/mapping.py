@@ -10,10 +10,16 @@ blocks are deterministic functions of their input).
 """
 from __future__ import annotations
 
+import _compat_pickle
+import copyreg
 import ctypes as C
+import functools
 import os
+import pickle
 import sys
-from typing import Dict, List, Optional, Sequence
+import types
+from collections import OrderedDict
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
 
@@ -229,31 +235,124 @@ class GuidingConditioner:
 
 
 # ---- checkpoint readers (SURVEY section 5 'checkpoint / resume') -----------------------------------
+def _module_tree_state_dict(mod, prefix: str = "", out=None) -> Dict[str, torch.Tensor]:
+    """state_dict of a rebuilt module tree, read from the pickled attribute dicts themselves (`_parameters`, `_buffers` minus the
+    non-persistent ones, `_modules`): what nn.Module.state_dict() returns, without relying on hook tables that a module pickled by
+    torch 1.10 (requirements.txt:59) does not carry."""
+    out = OrderedDict() if out is None else out
+    d = mod.__dict__
+    for k, v in (d.get("_parameters") or {}).items():
+        if v is not None:
+            out[prefix + k] = v.detach()
+    skip = d.get("_non_persistent_buffers_set") or ()
+    for k, v in (d.get("_buffers") or {}).items():
+        if v is not None and k not in skip:
+            out[prefix + k] = v.detach()
+    for k, sub in (d.get("_modules") or {}).items():
+        if sub is not None:
+            _module_tree_state_dict(sub, prefix + k + ".", out)
+    return out
+
+
 def _to_state_dict(obj) -> Dict[str, torch.Tensor]:
     if isinstance(obj, dict):
         return obj.get("state_dict", obj)
-    if hasattr(obj, "state_dict"):
-        return obj.state_dict()
+    if isinstance(obj, torch.nn.Module):
+        return _module_tree_state_dict(obj)
     raise TypeError(f"cannot extract a state_dict from {type(obj)}")
 
 
-def load_pickled(path: str) -> Dict[str, torch.Tensor]:
-    """Whole-module pickles as the reference writes them (mapping/train_transformer.py:166,
-    mapping/train_mapping.py:160) or plain state_dicts.  torch >= 2.6 needs weights_only=False for
-    module pickles; the classes must be importable (timm; mlp.py next to the checkpoints)."""
+class _SkeletonUnpickler(pickle.Unpickler):
+    """Rebuilds a pickled nn.Module TREE without the classes that defined it.  The reference saves the mapping network as whole
+    module objects (mapping/train_transformer.py:166: the timm 0.4.12 ViT; mapping/train_mapping.py:160: mlp.Classifier) and reads
+    them back with torch.load at classification_train_separately.py:255-269, which needs `timm` and `mlp.py` importable.  Only the
+    tensors matter here, so:
+      * torch's own weights_only allow-list (tensor / storage / parameter rebuilders, OrderedDict, dtypes ...) resolves as usual;
+      * `copyreg._reconstructor` + `builtins.object` (how protocol-2 pickles rebuild any plain object) and `functools.partial`
+        (an inert constructor) are let through;
+      * a class under torch.nn.modules (Linear, LayerNorm, Conv2d, Sequential, GELU ...) resolves to itself -- it is only ever
+        instantiated by object.__new__ + a __dict__ update, no code of it runs;
+      * any global of a THIRD-PARTY or missing module (timm.*, mlp.*, models.* ...) becomes a bare nn.Module subclass of the same
+        name, WITHOUT importing anything: its instances are inert containers of `_parameters` / `_buffers` / `_modules`;
+      * everything else -- a global of the standard library, of builtins, of torch or numpy that is not on the allow-list
+        (os.system, builtins.eval, torch.hub.load ...) -- is refused, as the weights_only unpickler refuses it."""
+    _PASS = {("copyreg", "_reconstructor"): copyreg._reconstructor, ("builtins", "object"): object,
+             ("functools", "partial"): functools.partial}
+    _stubs: Dict[Tuple[str, str], type] = {}
+
+    @staticmethod
+    def _allowed():
+        try:
+            from torch._weights_only_unpickler import _get_allowed_globals
+            return _get_allowed_globals()
+        except Exception:                                    # private API moved: fall back to the few globals a module pickle needs
+            import collections
+            return {"collections.OrderedDict": collections.OrderedDict, "torch._utils._rebuild_tensor_v2": torch._utils._rebuild_tensor_v2,
+                    "torch._utils._rebuild_parameter": torch._utils._rebuild_parameter, "torch.FloatStorage": torch.FloatStorage,
+                    "torch.LongStorage": torch.LongStorage, "torch.nn.parameter.Parameter": torch.nn.Parameter,
+                    "builtins.set": set, "torch.Size": torch.Size}
+
+    def find_class(self, module, name):
+        # protocol < 3 pickles (what torch.save writes) carry Python-2 names: __builtin__.set, copy_reg._reconstructor ...
+        if (module, name) in _compat_pickle.NAME_MAPPING:
+            module, name = _compat_pickle.NAME_MAPPING[(module, name)]
+        elif module in _compat_pickle.IMPORT_MAPPING:
+            module = _compat_pickle.IMPORT_MAPPING[module]
+        allowed = self._allowed()
+        full = f"{module}.{name}"
+        if full in allowed:
+            return allowed[full]
+        if (module, name) in self._PASS:
+            return self._PASS[(module, name)]
+        top = module.split(".")[0]
+        if module.startswith("torch.nn.modules"):
+            cls = getattr(sys.modules.get(module), name, None)
+            if isinstance(cls, type) and issubclass(cls, torch.nn.Module):
+                return cls
+        if top in sys.stdlib_module_names or top in ("builtins", "torch", "numpy", "nested_diffusion_amd"):
+            raise pickle.UnpicklingError(f"refusing global {full}: not needed to rebuild a module tree (only tensors are read; "
+                                         f"see nested_diffusion_amd.mapping._SkeletonUnpickler)")
+        key = (module, name)
+        if key not in self._stubs:
+            self._stubs[key] = type(name, (torch.nn.Module,), {"__module__": module, "__doc__": f"skeleton of {full} (state only)"})
+        return self._stubs[key]
+
+
+def _skeleton_pickle_module():
+    """A `pickle_module` for torch.load whose Unpickler is _SkeletonUnpickler."""
+    m = types.ModuleType("nd_skeleton_pickle")
+    for k in dir(pickle):
+        if not k.startswith("__"):
+            setattr(m, k, getattr(pickle, k))
+    m.Unpickler = _SkeletonUnpickler
+    m.load = lambda f, **kw: _SkeletonUnpickler(f, **kw).load()
+    return m
+
+
+def load_checkpoint_object(path: str):
+    """torch.load with the restricted unpickler, falling back to the skeleton unpickler (never to arbitrary-code unpickling)."""
     try:
-        obj = torch.load(path, map_location="cpu", weights_only=True)
+        return torch.load(path, map_location="cpu", weights_only=True)
     except Exception:
-        obj = torch.load(path, map_location="cpu", weights_only=False)
-    return _to_state_dict(obj)
+        return torch.load(path, map_location="cpu", weights_only=False, pickle_module=_skeleton_pickle_module())
 
 
-def load_conditioner(trained_path: str, dataset: str, device="cuda", num_heads: int = 12, dtype="f32") -> GuidingConditioner:
+def load_pickled(path: str) -> Dict[str, torch.Tensor]:
+    """Whole-module pickles as the reference writes them (mapping/train_transformer.py:166, mapping/train_mapping.py:160) or plain
+    state_dicts (also under a 'state_dict' key).  Plain files load with weights_only=True; module pickles are rebuilt as skeleton
+    trees by _SkeletonUnpickler and their tensors collected -- neither `timm` nor `mlp.py` has to be importable (the reference
+    needs both, :255-269), so the reference's own checkpoint files open on a box that has only this package."""
+    return _to_state_dict(load_checkpoint_object(path))
+
+
+def load_conditioner(trained_path: str, dataset: str, device="cuda", num_heads: Optional[int] = None, dtype="f32") -> GuidingConditioner:
     """classification_train_separately.py:252-275: <path>/vit_base_patch16_224_<Dataset>.pth and every
     file of sorted(os.listdir(<path>/MLPs))."""
-    if trained_path not in sys.path:
-        sys.path.append(trained_path)                      # so the pickled `mlp.Classifier` resolves (:255)
     vit_sd = load_pickled(os.path.join(trained_path, f"vit_base_patch16_224_{dataset}.pth"))
     mlp_dir = os.path.join(trained_path, "MLPs")
     mlps = [Classifier(load_pickled(os.path.join(mlp_dir, f)), device, dtype) for f in sorted(os.listdir(mlp_dir))]
+    if num_heads is None:
+        # the head count is not in a state_dict; the attention kernels take head dim 64 only (vit_base_patch16_224: 768 / 12), so it
+        # follows from the embedding width
+        num_heads = max(1, vit_sd["patch_embed.proj.weight"].shape[0] // 64)
     return GuidingConditioner(VisionTransformer(vit_sd, num_heads, device, dtype), mlps)

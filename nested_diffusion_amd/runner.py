@@ -18,7 +18,7 @@ import torch
 from . import ops
 from .diffusion_utils import make_beta_schedule
 from .engine import EnsembleEngine
-from .mapping import GuidingConditioner, load_conditioner
+from .mapping import GuidingConditioner, load_checkpoint_object, load_conditioner
 from . import dist as nd_dist
 
 CHEST = ['ChestXRay', 'ChestXRayAtkFGSM', 'ChestXRayAtkPGD', 'ChestXRayAtkBIM', 'ChestXRayAtkAUTOPGD', 'ChestXRayAtkCW',
@@ -127,7 +127,7 @@ class Diffusion(object):
             paths = cfg.diffusion.trained_diffusion_ckpt_path[0]
             states = []
             for i in range(min(len(paths), self.num_noise_estimators_required)):
-                state = torch.load(paths[i], map_location="cpu", weights_only=False)
+                state = load_checkpoint_object(paths[i])      # {'noise_estimator': state_dict, 'optimizer': ..., 'epoch': ...} (:1120-1126)
                 states.append(state["noise_estimator"])
                 logging.info("Diffusion model %d loaded", i)
             self._states = states
@@ -139,8 +139,17 @@ class Diffusion(object):
         for slot, i in enumerate(self.members):
             self.engine.load_member(slot, self._states[i])
         self.engine.set_schedule(self.alphas, self.one_minus_alphas_bar_sqrt)
-        self.engine.seed(self.seed or 0, first_image=0)          # in-library noise (predict_batch without a noise tensor)
+        self._seeded_first = None
+        self._seed_noise(0)            # in-library noise (predict_batch without a noise tensor)
         self._states = None            # device copies live in the engine
+
+    def _seed_noise(self, first_image: int) -> None:
+        """Seed the library's generator ONCE per (run, shard): nd_seed resets the device-side batch counter, so seeding again before
+        every pass over the data (each Nelder-Mead evaluation of `--calib` under ND_CALIB_RESAMPLE=1, or test_atk after it) would
+        replay identical noise.  Later passes just let the counter run on."""
+        if self._seeded_first != first_image:
+            self.engine.seed(self.seed or 0, first_image=first_image)
+            self._seeded_first = first_image
 
     # ---- the hot path (:749-794) --------------------------------------------------------------
     @torch.no_grad()
@@ -153,9 +162,9 @@ class Diffusion(object):
         (:767-777) and the aggregation (:786-789) are one hipGraph launch after the first batch of a shape."""
         if self.engine is None:
             raise RuntimeError("call load_noise_estimators() first")
-        if self.members != list(range(len(self.members))) or len(self.members) != len(self.cond_pred_model.mlps):
-            raise RuntimeError(f"member k is conditioned on mapping MLP k: {len(self.cond_pred_model.mlps)} MLPs need as many "
-                               f"noise estimators, {len(self.members)} are loaded")
+        if self.members != list(range(len(self.members))) or len(self.members) > len(self.cond_pred_model.mlps):
+            raise RuntimeError(f"member k is conditioned on mapping MLP k: the loaded noise estimators {self.members} must be "
+                               f"0..K-1 with K <= {len(self.cond_pred_model.mlps)} mapping MLPs")
         mc = mc_trials or self.mc_trials
         eng, T = self.engine, self.num_timesteps
         images_224 = ops._f32(images_224, "images")
@@ -198,7 +207,7 @@ class Diffusion(object):
             lo, hi = nd_dist.shard_bounds(B, rank, world)
             if self.engine is None:
                 self.load_noise_estimators(max_batch=max(hi - lo, 1))
-            self.engine.seed(self.seed or 0, first_image=lo)
+            self._seed_noise(lo)
             samples, targets = [], []
             for images_raw, target in test_loader:
                 images = self.shard_of_batch(images_raw, lo, hi)
@@ -252,7 +261,7 @@ class Diffusion(object):
         self.load_noise_estimators(max_batch=max(hi - lo, 1))
         # the sampler's draws come from the library's counter-based generator keyed on the GLOBAL image index (lo = this rank's
         # first image) and the batch counter: image i sees the same K*T*mc draws at any world size
-        self.engine.seed(self.seed or 0, first_image=lo)
+        self._seed_noise(lo)
         mv_class, target_class, prob_mc, piw_mc, var_mc = [], [], [], [], []
         n_step_img, t0 = 0, time.time()
         for images_raw, target in test_loader:

@@ -15,7 +15,12 @@ box).  The reference modules are imported unmodified from /root/reference:
   same kind of placeholder for absent, unused third-party imports.
 
 Only arrays (inputs + expected outputs) and seeds are written; no reference source text.
-Usage:  python tests/golden/gen_golden.py [--skip-full]
+Usage:  python tests/golden/gen_golden.py [--skip-full]            (re)write the fixtures
+        python tests/golden/gen_golden.py --check [--skip-full]    regenerate into a temporary directory and compare with the COMMITTED
+                                                                   files: same key sets, every array bit-identical (dtype, shape,
+                                                                   bytes); exit status 1 and a list of differences otherwise.
+                                                                   tests/test_golden_fixtures.py runs this whenever /root/reference
+                                                                   is present, so a drifted or hand-edited fixture cannot go unnoticed.
 """
 from __future__ import annotations
 
@@ -263,16 +268,12 @@ def gen_perturb(runner):
     print("perturb.npz")
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--skip-full", action="store_true")
-    ap.add_argument("--only", nargs="*", default=None, help="regenerate only these sampler cases (e.g. s4) and nothing else")
-    a = ap.parse_args()
+def generate(skip_full, only=None):
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     du, lm, ref_mlp = import_reference()
-    if a.only:
-        gen_sampler_small(du, lm, only=set(a.only))
+    if only:
+        gen_sampler_small(du, lm, only=set(only))
         return
     gen_schedule(du)
     gen_sampler_small(du, lm)
@@ -283,10 +284,56 @@ def main():
         gen_perturb(runner)
     except Exception as e:  # ordinary Python error -> recorded, aggregation stays self-pinned
         print("runner import failed:", type(e).__name__, e)
-    if not a.skip_full:
+    if not skip_full:
         gen_classifier(ref_mlp)
         gen_sampler_full(du, lm)
 
 
+def compare_trees(fresh_dir, committed_dir):
+    """Differences between freshly generated fixtures and the committed ones, as a list of strings (empty = identical)."""
+    diffs = []
+    for f in sorted(os.listdir(fresh_dir)):
+        if not f.endswith(".npz"):
+            continue
+        path = os.path.join(committed_dir, f)
+        if not os.path.exists(path):
+            diffs.append(f"{f}: generated but not committed")
+            continue
+        new, old = np.load(os.path.join(fresh_dir, f)), np.load(path)
+        if sorted(new.files) != sorted(old.files):
+            diffs.append(f"{f}: key sets differ: only generated {sorted(set(new.files) - set(old.files))}, "
+                         f"only committed {sorted(set(old.files) - set(new.files))}")
+        for k in sorted(set(new.files) & set(old.files)):
+            a, b = new[k], old[k]
+            if a.dtype != b.dtype or a.shape != b.shape or a.tobytes() != b.tobytes():
+                diffs.append(f"{f}[{k}]: committed array is not what the generator produces "
+                             f"({b.dtype}{b.shape} vs {a.dtype}{a.shape})")
+    return diffs
+
+
+def main():
+    global OUT
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--skip-full", action="store_true", help="leave out the two config-dim fixtures (2.6 GB of weights, minutes)")
+    ap.add_argument("--only", nargs="*", default=None, help="regenerate only these sampler cases (e.g. s4) and nothing else")
+    ap.add_argument("--check", action="store_true", help="regenerate to a temp dir and compare with the committed fixtures")
+    a = ap.parse_args()
+    if not a.check:
+        generate(a.skip_full, a.only)
+        return 0
+    import tempfile
+    committed = OUT
+    with tempfile.TemporaryDirectory(prefix="nd_golden_") as tmp:
+        OUT = tmp
+        generate(a.skip_full, a.only)
+        diffs = compare_trees(tmp, committed)
+        n = len([f for f in os.listdir(tmp) if f.endswith(".npz")])
+    OUT = committed
+    for d in diffs:
+        print("DIFF", d)
+    print(f"checked {n} fixture files against {committed}: {'identical' if not diffs else str(len(diffs)) + ' difference(s)'}")
+    return 1 if diffs else 0
+
+
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

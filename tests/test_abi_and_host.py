@@ -45,6 +45,13 @@ def test_abi_argument_validation_without_gpu():
     h = ctypes.c_void_p()
     assert lib.nd_create(ctypes.byref(cfg), ctypes.byref(h)) != 0
     assert b"data_dim" in lib.nd_last_error()
+    # library limits the reference does not have, stated in nd_config's comment: y_dim <= 8, n_members <= 255
+    for bad_cfg, word in ((_lib.NdConfig(9, 48, 64, 64, 10, 1, 4, 4), b"y_dim must be in [1,8]"),
+                          (_lib.NdConfig(2, 48, 64, 64, 10, 256, 4, 4), b"n_members")):
+        assert lib.nd_create(ctypes.byref(bad_cfg), ctypes.byref(h)) != 0
+        assert word in lib.nd_last_error(), lib.nd_last_error()
+    assert lib.nd_create(ctypes.byref(_lib.NdConfig(8, 48, 64, 64, 10, 255, 4, 4)), ctypes.byref(h)) == 0
+    assert lib.nd_destroy(h) == 0
     good = _lib.NdConfig(2, 150528, 4096, 4096, 100, 5, 32, 32)
     nbytes = lib.nd_workspace_bytes(ctypes.byref(good))
     # packed weights (5 x 2.74 GB) + tables + activations: 13..16 GB at the headline config

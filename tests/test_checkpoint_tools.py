@@ -1,11 +1,13 @@
-"""tools/convert_checkpoints.py: whole-module pickles (mapping/train_transformer.py:166, mapping/train_mapping.py:160) ->
-plain state_dict files in the same layout, readable with weights_only=True by nested_diffusion_amd.mapping.load_pickled."""
+"""The reference's whole-module checkpoint pickles (mapping/train_transformer.py:166, mapping/train_mapping.py:160) read WITHOUT the
+classes that defined them: directly by nested_diffusion_amd.mapping.load_pickled (skeleton unpickler), and through
+tools/convert_checkpoints.py (-> plain state_dict files in the same layout, readable with weights_only=True)."""
 import importlib.util
 import os
 import subprocess
 import sys
 import textwrap
 
+import pytest
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -82,3 +84,97 @@ def test_converter_rejects_non_checkpoints(tmp_path):
     except TypeError:
         raised = True
     assert raised
+
+
+# a module tree shaped like the reference's pickles: nested containers, buffers (one non-persistent), plain python attributes --
+# defined in a module that only the WRITING process can import, under a package path like timm's
+TREE_SRC = textwrap.dedent('''
+    import torch, torch.nn as nn
+    class Attention(nn.Module):
+        def __init__(self, dim=8, heads=2):
+            super().__init__()
+            self.num_heads, self.scale = heads, (dim // heads) ** -0.5
+            self.qkv, self.proj = nn.Linear(dim, 3 * dim), nn.Linear(dim, dim)
+            self.attn_drop = nn.Dropout(0.0)
+    class Block(nn.Module):
+        def __init__(self, dim=8):
+            super().__init__()
+            self.norm1, self.attn = nn.LayerNorm(dim, eps=1e-6), Attention(dim)
+            self.drop_path = nn.Identity()
+            self.mlp = nn.Sequential(nn.Linear(dim, 16), nn.GELU(), nn.Linear(16, dim))
+    class VisionTransformer(nn.Module):
+        def __init__(self, dim=8):
+            super().__init__()
+            self.num_features = self.embed_dim = dim
+            self.cls_token = nn.Parameter(torch.randn(1, 1, dim))
+            self.patch_embed = nn.Conv2d(3, dim, 4, 4)
+            self.blocks = nn.Sequential(Block(dim), Block(dim))
+            self.bn = nn.BatchNorm1d(dim)                          # buffers: running_mean / running_var / num_batches_tracked
+            self.register_buffer("scratch", torch.zeros(3), persistent=False)
+            self.head = nn.Linear(dim, 2)
+''')
+
+
+def _write_tree(tmp_path):
+    pkg = tmp_path / "site" / "timmlike" / "models"
+    pkg.mkdir(parents=True)
+    (tmp_path / "site" / "timmlike" / "__init__.py").write_text("")
+    (pkg / "__init__.py").write_text("")
+    (pkg / "vision_transformer.py").write_text(TREE_SRC)
+    writer = textwrap.dedent(f'''
+        import sys, torch
+        sys.path.insert(0, {str(tmp_path / "site")!r})
+        from timmlike.models.vision_transformer import VisionTransformer
+        torch.manual_seed(11)
+        m = VisionTransformer().eval()
+        torch.save(m, {str(tmp_path / "module.pth")!r})                                          # zip format (torch >= 1.6 default)
+        torch.save(m, {str(tmp_path / "module_legacy.pth")!r}, _use_new_zipfile_serialization=False)
+        torch.save(m.state_dict(), {str(tmp_path / "state.pth")!r})
+    ''')
+    subprocess.run([sys.executable, "-c", writer], check=True)
+
+
+def test_module_pickles_load_directly_without_their_classes(tmp_path):
+    """mapping.load_pickled on a whole-module pickle whose classes exist nowhere in this process: same names, order and values as the
+    module's own state_dict() (nested sub-modules, parameters, persistent buffers; the non-persistent buffer left out)."""
+    import warnings
+    from nested_diffusion_amd.mapping import load_pickled
+    _write_tree(tmp_path)
+    assert "timmlike" not in sys.modules
+    want = torch.load(tmp_path / "state.pth", map_location="cpu", weights_only=True)
+    assert "blocks.1.attn.qkv.weight" in want and "bn.running_var" in want and "scratch" not in want
+    for name in ("module.pth", "module_legacy.pth"):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")                        # legacy format: "couldn't retrieve source code for container"
+            got = load_pickled(str(tmp_path / name))
+        assert list(got) == list(want), name
+        for k in want:
+            assert torch.equal(got[k], want[k]) and got[k].dtype == want[k].dtype, (name, k)
+    assert "timmlike" not in sys.modules                           # nothing was imported to do it
+
+
+def test_skeleton_unpickler_still_refuses_other_globals(tmp_path):
+    """Only module trees get the lenient treatment: a pickle that names a standard-library / builtins / torch global outside
+    torch's weights_only allow-list is refused before anything is called."""
+    import pickle
+    from nested_diffusion_amd.mapping import load_pickled
+    marker = tmp_path / "executed"
+
+    class RunsACommand:
+        def __reduce__(self):
+            return (os.system, (f"touch {marker}",))
+
+    class Evals:
+        def __reduce__(self):
+            return (eval, ("1+1",))
+
+    class CallsTorchHub:
+        def __reduce__(self):
+            return (torch.hub.load, ("x", "y"))
+
+    for i, bad in enumerate((RunsACommand(), Evals(), CallsTorchHub())):
+        path = tmp_path / f"bad{i}.pth"
+        torch.save({"weights": torch.zeros(2), "extra": bad}, path)
+        with pytest.raises(pickle.UnpicklingError, match="refusing global"):
+            load_pickled(str(path))
+    assert not marker.exists()

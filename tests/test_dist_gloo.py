@@ -54,6 +54,36 @@ def test_batch_sharding_and_single_all_gather_world2(tmp_path, n_total):
         assert res["ok"], (r, n_total)
 
 
+def test_configs3_group_shape_world8_256_rows(tmp_path):
+    """BASELINE configs[3]'s group: 8 ranks x 32 rows = one batch of 256, gathered with the single all-gather (gloo, CPU tensors)."""
+    world, n_total = 8, 256
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, n_total, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert torch.load(os.path.join(str(tmp_path), f"r{r}.pt"))["ok"], r
+
+
+@pytest.mark.parametrize("world,n_total", [(8, 256), (3, 10), (4, 7)])
+def test_emulated_ranks_assemble_what_the_collective_returns(world, n_total):
+    """dist.emulate_rank (the one-process rehearsal the GPU tests use for world sizes the box cannot host as processes): after the
+    last rank's pass all_gather_rows returns exactly the concatenation of the shards -- ragged splits included -- and rank_world()
+    reported each (rank, world) on the way; switched off, the process is a single rank again."""
+    from nested_diffusion_amd import dist as nd_dist
+    full = torch.arange(n_total * 3, dtype=torch.float32).reshape(n_total, 3) + 1.0
+    sink, out = {}, None
+    try:
+        for r in range(world):
+            nd_dist.emulate_rank(r, world, sink)
+            assert nd_dist.rank_world() == (r, world)
+            lo, hi = nd_dist.shard_bounds(n_total, r, world)
+            out = nd_dist.all_gather_rows(full[lo:hi].clone(), n_total)
+            assert out.shape == full.shape and torch.equal(out[:hi], full[:hi]) and not out[hi:].any()
+    finally:
+        nd_dist.emulate_rank()
+    assert torch.equal(out, full) and sorted(sink) == list(range(world))
+    assert nd_dist.rank_world() == (0, 1)
+
+
 def test_single_process_is_a_noop():
     from nested_diffusion_amd import dist as nd_dist
     assert nd_dist.rank_world() == (0, 1)

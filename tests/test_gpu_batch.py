@@ -101,6 +101,26 @@ def test_sampler_draws_its_own_noise_and_advances_the_batch_counter():
     assert not torch.equal(eng.sample(yhat, yhat, None, mc=mc), a0)
 
 
+def test_member_range_draws_the_members_own_noise():
+    """A member's in-library draws depend on its index in the ENSEMBLE, not on its position in the call: sampling member 1 alone
+    equals member 1 of the full-range noise (nd_rng.hip counter word 1 = trial | (m0 + k) << 16 | quad << 24), graph and eager."""
+    K, T, B, mc, Cc = 2, 6, 5, 2, 2
+    eng, _, _ = _small_engine(K, T, B, mc, Cc)
+    g = torch.Generator().manual_seed(2)
+    eng.encode(torch.rand(B, 48, generator=g))
+    yhat = torch.softmax(torch.randn(K, B, Cc, generator=g), -1).cuda()
+    for ctr, use_graph in enumerate((True, False)):
+        eng.seed(777, first_image=3)
+        for _ in range(ctr):                                          # advance to batch counter `ctr`
+            eng.sample(yhat, yhat, None, mc=mc)
+        alone = eng.sample(yhat[1:], yhat[1:], None, member0=1, n_members=1, mc=mc, use_graph=use_graph)
+        full = _normal(K, T, B, mc, Cc, 777, batch=ctr, first=3)
+        want = eng.sample(yhat[1:], yhat[1:], full[1:].contiguous(), member0=1, n_members=1, mc=mc)
+        assert torch.equal(alone, want), use_graph
+        zero = eng.sample(yhat[1:], yhat[1:], full[:1].contiguous(), member0=1, n_members=1, mc=mc)
+        assert not torch.equal(alone, zero)                           # and NOT member 0's stream
+
+
 def _vit_and_mlps(embed=128, heads=2, depth=5, img=32, patch=16, K=5, widths=(64, 32, 32), seed=3):
     vp = ref_cpu.init_vit_params(embed=embed, depth=depth, patch=patch, img=img, seed=seed)
     n_tok = (img // patch) ** 2
@@ -301,8 +321,11 @@ def test_probes_do_not_change_results_and_report_intervals():
     for _ in range(2):                                            # eager + recording, then a replay
         probed = r.predict_batch(x, noise=nz)
     head, pair, rec, n = r.engine.profile_read()
+    # the probes are NODES of the recorded batch graph (stamped on every replay), not leftovers of the eager first call
+    assert r.engine.probe_nodes() == 4 * 8
     r.engine.set_profiling(False)
     assert n == 8 and head > 0 and pair > 0 and rec > 0 and rec < head and rec < pair
     for k in ("samples", "prob", "vote", "probs", "yhat"):
         assert torch.equal(plain[k], probed[k]), k
     assert torch.equal(r.predict_batch(x, noise=nz)["samples"], plain["samples"])
+    assert r.engine.probe_nodes() == 0                            # rebuilt with profiling off: no record node

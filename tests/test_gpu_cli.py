@@ -107,3 +107,117 @@ def test_calib_path_nelder_mead(tmp_path, capsys, monkeypatch):
     assert "Optimal t value:" in out and out.count("Ours ECE:") >= 10, out
     txt = open(os.path.join(str(tmp_path), "c", "logs", "cal", "split_0", "stdout.txt")).read()
     assert "Traceback" not in txt, txt
+
+
+# stand-ins with the parameter NAMES of timm 0.4.12's VisionTransformer and of mapping/models/mlp.py::Classifier, importable only in
+# the process that writes the pickles (as `timm` / `mlp` are importable only where the reference's environment is installed)
+_STANDIN_SRC = '''
+import torch, torch.nn as nn
+class PatchEmbed(nn.Module):
+    def __init__(s, img, patch, embed):
+        super().__init__(); s.img_size = (img, img); s.patch_size = (patch, patch); s.num_patches = (img // patch) ** 2
+        s.proj = nn.Conv2d(3, embed, patch, patch)
+class Attention(nn.Module):
+    def __init__(s, dim, heads):
+        super().__init__(); s.num_heads = heads; s.scale = (dim // heads) ** -0.5
+        s.qkv = nn.Linear(dim, dim * 3); s.attn_drop = nn.Dropout(0.0); s.proj = nn.Linear(dim, dim); s.proj_drop = nn.Dropout(0.0)
+class Mlp(nn.Module):
+    def __init__(s, dim, hidden):
+        super().__init__(); s.fc1 = nn.Linear(dim, hidden); s.act = nn.GELU(); s.fc2 = nn.Linear(hidden, dim); s.drop = nn.Dropout(0.0)
+class Block(nn.Module):
+    def __init__(s, dim, heads):
+        super().__init__(); s.norm1 = nn.LayerNorm(dim, eps=1e-6); s.attn = Attention(dim, heads); s.drop_path = nn.Identity()
+        s.norm2 = nn.LayerNorm(dim, eps=1e-6); s.mlp = Mlp(dim, 4 * dim)
+class VisionTransformer(nn.Module):
+    def __init__(s, img, patch, embed, depth, heads, num_classes):
+        super().__init__(); s.num_classes = num_classes; s.num_features = s.embed_dim = embed
+        s.patch_embed = PatchEmbed(img, patch, embed)
+        s.cls_token = nn.Parameter(torch.zeros(1, 1, embed)); s.pos_embed = nn.Parameter(torch.zeros(1, s.patch_embed.num_patches + 1, embed))
+        s.pos_drop = nn.Dropout(0.0); s.blocks = nn.Sequential(*[Block(embed, heads) for _ in range(depth)])
+        s.norm = nn.LayerNorm(embed, eps=1e-6); s.pre_logits = nn.Identity(); s.head = nn.Linear(embed, num_classes)
+class Classifier(nn.Module):
+    def __init__(s, n_in, widths, num_classes):
+        super().__init__(); s.in_features = n_in
+        s.linear1 = nn.Linear(n_in, widths[0]); s.linear2 = nn.Linear(widths[0], widths[1]); s.linear3 = nn.Linear(widths[1], widths[2])
+        s.linear4 = nn.Linear(widths[2], num_classes); s.relu = nn.ReLU(); s.dropout = nn.Dropout(0.5)
+'''
+
+
+def test_load_conditioner_reads_whole_module_pickles_directly(tmp_path):
+    """classification_train_separately.py:255-269 loads <path>/vit_base_patch16_224_<Dataset>.pth and <path>/MLPs/* as pickled MODULE
+    objects (mapping/train_transformer.py:166, mapping/train_mapping.py:160).  Files of exactly that kind, written by another
+    process that has the defining classes, go straight through mapping.load_conditioner here -- no converter run, no sys.path
+    entry -- and give the guiding predictions of the same weights handed over as state_dicts."""
+    import subprocess
+    import sys
+    import textwrap
+    from nested_diffusion_amd import mapping
+    embed, heads, depth, img, patch, C, K, widths = 128, 2, 5, 32, 16, 2, 3, (64, 32, 16)
+    vp = ref_cpu.init_vit_params(embed=embed, depth=depth, patch=patch, img=img, seed=3)
+    n_tok = (img // patch) ** 2
+    mlps = [ref_cpu.init_classifier_params(n_tok * embed, widths=widths, seed=20 + i) for i in range(K)]
+    plain, ck = tmp_path / "plain", tmp_path / "ckpt"
+    (plain / "MLPs").mkdir(parents=True); (ck / "MLPs").mkdir(parents=True)
+    torch.save(vp, plain / "vit.pth")
+    for i, m in enumerate(mlps):
+        torch.save(m, plain / "MLPs" / f"block_{i}.pth")
+    site = tmp_path / "site"
+    site.mkdir()
+    (site / "standin_models.py").write_text(_STANDIN_SRC)
+    writer = textwrap.dedent(f'''
+        import sys, torch
+        sys.path.insert(0, {str(site)!r})
+        import standin_models as sm
+        vit = sm.VisionTransformer({img}, {patch}, {embed}, {depth}, {heads}, {C}).eval()
+        vit.load_state_dict(torch.load({str(plain / "vit.pth")!r}), strict=True)
+        torch.save(vit, {str(ck / "vit_base_patch16_224_ChestXRay.pth")!r})
+        for i in range({K}):
+            m = sm.Classifier({n_tok * embed}, {widths!r}, {C}).eval()
+            m.load_state_dict(torch.load({str(plain / "MLPs")!r} + f"/block_{{i}}.pth"), strict=True)
+            torch.save(m, {str(ck / "MLPs")!r} + f"/block_{{i}}.pth")
+    ''')
+    subprocess.run([sys.executable, "-c", writer], check=True)
+    assert "standin_models" not in sys.modules and str(site) not in sys.path
+    cond = mapping.load_conditioner(str(ck), "ChestXRay", num_heads=heads)
+    want = mapping.GuidingConditioner(mapping.VisionTransformer(vp, heads), [mapping.Classifier(m) for m in mlps])
+    x = torch.rand(4, 3, img, img, generator=torch.Generator().manual_seed(9)).cuda()
+    got, ref = cond.compute_guiding_prediction(x, include_full_vit=True), want.compute_guiding_prediction(x, include_full_vit=True)
+    assert len(got) == K + 1
+    for a, b in zip(got, ref):
+        assert torch.equal(a, b)
+    assert "standin_models" not in sys.modules
+
+
+def test_literal_test_sh_command_line_from_the_shim_directory(tmp_path):
+    """diffusion/testing_scripts/test.sh:24 as written -- `python main.py --test --device 0 --thread 8 --loss ... --config
+    configs/${TASK}.yml --exp ./results/$TASK/${MODEL_VERSION_DIR} --doc ${TASK} ...` with the working directory at main.py's own
+    directory and relative config / experiment paths -- through scripts/diffusion/main.py in a fresh interpreter.  Only
+    `--synthetic_batches 1 --timesteps 6` are added (no dataset exists on the box; the tiny checkpoints have 6 steps)."""
+    import shutil
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    shim_dir = os.path.join(root, "scripts", "diffusion")
+    task = f"nd_test_{os.getpid()}"
+    ypath, *_ = _write_run(str(tmp_path), T=6, K=5, B=4)
+    os.makedirs(os.path.join(shim_dir, "configs"), exist_ok=True)
+    cfg_rel = os.path.join("configs", f"{task}.yml")
+    shutil.copy(ypath, os.path.join(shim_dir, cfg_rel))
+    version_dir = "card_onehot_conditional_results/1000steps/nn/run_0/f_phi_prior_cat_f_phi/f_phi_supervised"       # test.sh:1-7
+    exp_rel = f"./results/{task}/{version_dir}"
+    argv = ["main.py", "--test", "--device", "0", "--thread", "8", "--loss", "card_onehot_conditional", "--config", cfg_rel,
+            "--exp", exp_rel, "--doc", task, "--n_splits", "1", "--noise_perturbation", "0", "--low_resolution", "0",
+            "--brightness", "0", "--contrast", "1", "--crop", "0", "--attack_name", "None", "--eps", "0", "--ni",
+            "--preprocess", "grayscaled"] + ["--synthetic_batches", "1", "--timesteps", "6"]
+    try:
+        r = subprocess.run([sys.executable] + argv, cwd=shim_dir, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        log = os.path.join(shim_dir, "results", task, version_dir, "logs", task, "split_0")
+        txt = open(os.path.join(log, "stdout.txt")).read()
+        assert "Traceback" not in txt and "Testing procedure finished" in txt, txt
+        assert os.path.exists(os.path.join(log, "config.yml"))
+        for key in ("Majority voting accuracy for MC:", "ECE:", "Average correct PIW per class:", "Average incorrect variances per class:"):
+            assert key in r.stdout + r.stderr + txt, key
+    finally:
+        shutil.rmtree(os.path.join(shim_dir, "results", task), ignore_errors=True)
+        os.remove(os.path.join(shim_dir, cfg_rel))

@@ -35,7 +35,7 @@ def _run_ranks(world, out, backend, extra=()):
     port = _free_port()
     procs = []
     for r in range(world):
-        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))      # HSA_ENABLE_IPC_MODE_LEGACY: set by nested_diffusion_amd/dist.py in every rank
         if world > 1:
             env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), ND_DIST_BACKEND=backend)
         else:
@@ -73,6 +73,32 @@ def test_config3_two_ranks_at_config_dims_equal_one_process(tmp_path):
     assert a["accuracy"] == b["accuracy"]
 
 
+def test_config3_real_shape_8_shards_of_32_equal_one_process_of_256(tmp_path):
+    """configs[3] at its REAL shape -- batch 256 as 8 ranks x 32 rows at config dims -- against one process holding all 256 rows.
+    The two sides cross kernel families: a 32-row shard streams through k_skinny, the 256-row batch goes through the LDS-tiled
+    k_cond_gemm.  A GPU box admits at most 6 processes on its card, so the 8 ranks are rehearsed one after the other in ONE
+    process (dist.emulate_rank: same shard bounds, same first-image noise index, same padding / unpadding around the gather; the
+    collective itself at world 8 runs over gloo in tests/test_dist_gloo.py, over RCCL on the driver's 8-GPU node)."""
+    torch.cuda.empty_cache()
+    one, eight = str(tmp_path / "w1.pt"), str(tmp_path / "w8.pt")
+    _run_ranks(1, one, "gloo", extra=("--global-batch", "256"))
+    _run_ranks(1, eight, "gloo", extra=("--global-batch", "256", "--emulate-world", "8"))
+    a, b = torch.load(one), torch.load(eight)
+    assert a["world"] == 1 and b["world"] == 8 and b["shards"] == list(range(8))
+    assert a["rows_per_rank"] == 256 and b["rows_per_rank"] == 32
+    assert a["step_kernel"] == "k_cond_gemm" and b["step_kernel"] == "k_skinny"
+    assert a["prob"].shape == b["prob"].shape == (256, 2)
+    err = float((a["prob"] - b["prob"]).abs().max())
+    msg = (f"configs[3] real shape at config dims: 8 x 32-row shards (k_skinny) vs 1 x 256 rows (k_cond_gemm): "
+           f"max |class-prob delta| = {err:.2e}, accuracy {b['accuracy']:.4f} vs {a['accuracy']:.4f}")
+    print(msg)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "r4_config3_real_shape.log"), "w") as f:
+        f.write(msg + "\n")
+    assert err <= 2e-6, err
+    assert a["accuracy"] == b["accuracy"]
+
+
 def test_bench_gpus2_launches_its_own_ranks():
     """`python bench.py --gpus 2` invoked PLAINLY (no torchrun): the parent starts both ranks before touching the GPU and
     relays rank 0's single JSON line.  Ranks share cuda:0 over gloo when the box has one GPU."""
@@ -92,6 +118,25 @@ def test_bench_gpus2_launches_its_own_ranks():
     assert line["value"] > 0 and line["config"]["global_batch"] == 64 and line["scaling"] == "weak"
     assert line["dist_backend"] == ("gloo" if torch.cuda.device_count() < 2 else "nccl")
     print("bench --gpus 2:", line["value"], "step*img/s,", line["ms_per_step"], "ms/step,", line["dist_backend"])
+
+
+def test_bench_rccl_call_sequence_in_a_one_rank_group():
+    """Every RCCL call bench.py makes at N > 1 -- init_process_group('nccl', device_id=...), barrier(device_ids=...) on both sides of
+    the timed region, all_reduce(MAX) of the step time on a DEVICE tensor, all_gather_into_tensor of the batch's probabilities on
+    HBM tensors, destroy_process_group -- executed on the production backend in a ONE-rank group (ND_FORCE_DIST=1): what a one-GPU
+    box can run of the sequence before the driver's 8-GPU node does."""
+    torch.cuda.empty_cache()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "ND_DIST_BACKEND")}
+    env["ND_FORCE_DIST"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["dist_backend"] == "nccl" and line["n_ranks_seen"] == 1 and line["n_gpus"] == 1
+    assert line["collective_checked"] is True and line["value"] > 0
+    print("bench under ND_FORCE_DIST=1 (1-rank RCCL group):", line["value"], "step*img/s,", line["ms_per_step"], "ms/step")
 
 
 def test_bench_refuses_more_ranks_than_gpus_on_rccl():

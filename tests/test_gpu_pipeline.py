@@ -100,6 +100,26 @@ def test_guidance_false_model_vs_reference_golden():
     assert np.abs(e - z["eps_rows"]).max() < 5e-5 * max(1.0, np.abs(z["eps_rows"]).max())
 
 
+@pytest.mark.parametrize("name", ["s0", "s1", "s2", "s3", "s4"])
+def test_per_row_timesteps_vs_reference_golden(name):
+    """`eps_rows` of golden s0-s4: the REFERENCE's ConditionalModel.forward called with a [B] vector of timesteps
+    (latent_model.py:101-105, 169-184) -- guidance=True models, C = 2 and 3, B = 1..32, T = 10..1000 (s3 / s4 index embedding rows
+    up to 999) -- against the nn.Module mirror on the GPU."""
+    import os
+    import numpy as np
+    from nested_diffusion_amd.latent_model import ConditionalModel
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", f"sampler_{name}.npz"))
+    p = {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("p.")}
+    D, H, Fd, C, T, B, seed = [int(v) for v in z["dims"]]
+    model = ConditionalModel(small_config(D, H, Fd, C, T, B), guidance=True, max_batch=max(B, 8))
+    model.load_state_dict(p)
+    model = model.cuda().eval()
+    x, yhat = torch.from_numpy(z["x"]).cuda(), torch.from_numpy(z["yhat"]).cuda()
+    e = model(x, torch.from_numpy(z["seq"][1]).cuda(), torch.from_numpy(z["t_rows"]).cuda(), yhat).cpu().numpy()
+    assert e.shape == z["eps_rows"].shape
+    assert np.abs(e - z["eps_rows"]).max() < 5e-5 * max(1.0, np.abs(z["eps_rows"]).max()), name
+
+
 def test_guidance_false_and_per_row_timesteps():
     """The two call shapes of ConditionalModel.forward the inference loop never uses (latent_model.py:157-158: lin1 on y_t
     alone; :101-105: gamma = embed(t) with one t PER ROW, the training-time call) against the oracle, and a whole reverse

@@ -4,18 +4,18 @@
 The reference saves the mapping network as pickled nn.Module OBJECTS:
     mapping/train_transformer.py:166   torch.save(model, .../vit_base_patch16_224_<Dataset>.pth)      (timm 0.4.12 ViT)
     mapping/train_mapping.py:160       torch.save(classifier, .../MLPs/<name>.pth)                    (mlp.Classifier)
-and loads them with torch.load at classification_train_separately.py:257, 266.  Unpickling such a file needs the defining
-packages importable (timm==0.4.12, requirements.txt:58; `mlp.py` on sys.path, :255).  The GPU boxes of this build have
-neither, and nested_diffusion_amd.mapping only needs the tensors.  Run this script ONCE on any machine where the reference's
-environment is installed (CPU is enough; it never runs on the GPU box):
+and loads them with torch.load at classification_train_separately.py:257, 266, which needs the defining packages importable
+(timm==0.4.12, requirements.txt:58; `mlp.py` on sys.path, :255).  nested_diffusion_amd.mapping.load_pickled does NOT need them: it
+rebuilds such a pickle as a skeleton module tree and reads the tensors (mapping._SkeletonUnpickler), so the reference's files can be
+pointed at directly.  This script is the optional one-off that rewrites them as plain state_dicts -- smaller to audit, loadable with
+weights_only=True by anything -- on any machine, with or without the reference's environment:
 
-    python tools/convert_checkpoints.py --src <trained_aux_cls_ckpt_path> --dst <new_dir> [--sys-path <dir with mlp.py>]
+    python tools/convert_checkpoints.py --src <trained_aux_cls_ckpt_path> --dst <new_dir>
 
 Every *.pth under --src (the ViT file and MLPs/*.pth) is rewritten under --dst with the same relative path as a plain
-{name: tensor} state_dict, which `nested_diffusion_amd.mapping.load_pickled` reads with weights_only=True -- point
-`diffusion.trained_aux_cls_ckpt_path` of the YAML at --dst.  Files that already are state_dicts (or dicts holding one under
-'state_dict') are copied through unchanged in content.  The noise-estimator checkpoints (dict with key 'noise_estimator',
-classification_train_separately.py:1120-1126) are plain tensors already and need no conversion.
+{name: tensor} state_dict -- point `diffusion.trained_aux_cls_ckpt_path` of the YAML at --dst.  Files that already are state_dicts
+(or dicts holding one under 'state_dict') are copied through unchanged in content.  The noise-estimator checkpoints (dict with key
+'noise_estimator', classification_train_separately.py:1120-1126) are plain tensors already and need no conversion.
 """
 from __future__ import annotations
 
@@ -38,9 +38,18 @@ def to_state_dict(obj):
     raise TypeError(f"cannot extract a state_dict from {type(obj).__name__}")
 
 
+def _load_any(src: str):
+    """Plain files with the restricted unpickler; module pickles as skeleton trees (no class of theirs is imported or run)."""
+    try:
+        return torch.load(src, map_location="cpu", weights_only=True)
+    except Exception:
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from nested_diffusion_amd.mapping import load_pickled
+        return load_pickled(src)
+
+
 def convert_file(src: str, dst: str) -> int:
-    obj = torch.load(src, map_location="cpu", weights_only=False)       # module pickles need the full unpickler (torch >= 2.6: Q11)
-    sd = OrderedDict((k, v.detach().clone().contiguous()) for k, v in to_state_dict(obj).items())
+    sd = OrderedDict((k, v.detach().clone().contiguous()) for k, v in to_state_dict(_load_any(src)).items())
     os.makedirs(os.path.dirname(dst) or ".", exist_ok=True)
     torch.save(sd, dst)
     torch.load(dst, map_location="cpu", weights_only=True)             # must be readable without any class on sys.path
@@ -48,9 +57,6 @@ def convert_file(src: str, dst: str) -> int:
 
 
 def convert_tree(src_root: str, dst_root: str, sys_paths=()) -> dict:
-    for p in (src_root, *sys_paths):                                   # classification_train_separately.py:255
-        if p and p not in sys.path:
-            sys.path.append(p)
     done = {}
     for dirpath, _, files in os.walk(src_root):
         for f in sorted(files):
@@ -66,7 +72,7 @@ def main(argv=None) -> int:
     ap = argparse.ArgumentParser(description=__doc__.split("\n\n")[0])
     ap.add_argument("--src", required=True, help="the reference's trained_aux_cls_ckpt_path (holds vit_base_patch16_224_*.pth and MLPs/)")
     ap.add_argument("--dst", required=True, help="output directory (same layout, plain state_dicts)")
-    ap.add_argument("--sys-path", action="append", default=[], help="extra import roots for the pickled classes (e.g. mapping/models)")
+    ap.add_argument("--sys-path", action="append", default=[], help="accepted for old command lines; no longer needed (nothing is imported)")
     a = ap.parse_args(argv)
     if os.path.abspath(a.src) == os.path.abspath(a.dst):
         raise SystemExit("--dst must differ from --src (the originals are kept)")
