@@ -153,6 +153,26 @@ def cpu_baseline(members_cpu, vit_cpu, mlps_cpu, images_cpu, out_gpu, noise, T_f
                       f"{T_full} steps with the encoder evaluated once per member, {t_samp:.1f} s"}
 
 
+def shape_traffic(dtype: str, M: int, K: int):
+    """(HBM-side bytes per step-block launch, where the number comes from) for this run's shape, REPLAYED from the committed PMC
+    profile profiles/traffic.json (tools/profile_round.sh pmc -> tools/pmc_traffic.py); (None, why) when the shape has no entry."""
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    key = f"{dtype}_M{M}_K{K}"
+    if not os.path.exists(tpath):
+        return None, "null: profiles/traffic.json is missing"
+    try:
+        prof = json.load(open(tpath))
+        ent = prof.get("entries", {}).get(key)
+    except Exception as e:
+        return None, f"null: profiles/traffic.json unreadable: {e}"
+    if ent is None:
+        return None, (f"null: no PMC profile is committed for this shape ({key}: dtype, rows per member, members); profiles/traffic.json "
+                      f"holds {sorted(prof.get('entries', {}))}")
+    return ent["step_block_bytes_per_launch"], (f"profiles/traffic.json[{key}] <- {prof.get('source')}: rocprofv3 PMC (FETCH_SIZE x2 + WRITE_SIZE, "
+                                                 "separate passes) of the step-block kernels at this shape, REPLAYED from the committed profile, "
+                                                 "not measured by this run; FETCH_SIZE counts Infinity-Cache hits too")
+
+
 def launch_ranks(n: int, argv) -> int:
     """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes (RANK / LOCAL_RANK / WORLD_SIZE /
     MASTER_* in their environment, one GPU each), let rank 0 print the JSON line on the inherited stdout, and return non-zero
@@ -349,32 +369,20 @@ def main():
                              "note": f"lin2 launches read {keep2 / 1e6:.0f} MB and lin3 launches {keep3 / 1e6:.0f} MB of weights out of the "
                                      "Infinity Cache (a memory-side cache: those bytes still cross the same fabric links to the XCDs)"}
                             if n_probe else None)
-        traffic, why = None, None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if not (args.dtype == "f32" and M == 32 and K == 5):
-            why = (f"no PMC profile is committed for this shape (dtype {args.dtype}, M = {M} rows, K = {K} members): profiles/traffic.json "
-                   "holds the counters of the headline shape only (f32, M = 32, K = 5)")
-        elif not os.path.exists(tpath):
-            why = "profiles/traffic.json is missing"
-        else:
-            try:
-                traffic = json.load(open(tpath)).get("k_skinny_bytes_per_launch")
-            except Exception as e:
-                why = f"profiles/traffic.json unreadable: {e}"
+        traffic, why = shape_traffic(args.dtype, M, K)
         roof["traffic"] = traffic
         # the same launches also issue K*2*M*F*F exact-f32 MFMA flop: at M = 32 rows that is 34 us of matrix-pipe time per launch,
         # so the kernel sits against BOTH the stream and the f32 matrix pipe (PMC SQ_VALU_MFMA_BUSY 0.55, profiles/r02_pmc_mfma.csv)
         roof["co_limit_mfma_frac"] = (K * 2.0 * M * F * F / (avg_us * 1e-6) / 1e12 / F32_MFMA_PEAK_TF) if (n_probe and args.dtype == "f32") else None
-        roof["traffic_source"] = ("profiles/traffic.json: rocprofv3 PMC (FETCH_SIZE x2 + WRITE_SIZE, separate passes) of this kernel at this "
-                                  "shape, REPLAYED from the committed profile, not measured by this run; FETCH_SIZE counts Infinity-Cache "
-                                  "hits too") if traffic else f"null: {why}"
+        roof["traffic_source"] = why
     else:
         # M = B*mc rows > 64: the blocks are compute-bound f32-MFMA GEMMs (2*M*F*F flop per member and launch)
         alg = K * 2.0 * M * F * F
         achieved = alg / (avg_us * 1e-6) / 1e12 if n_probe else None
         peak = F32_MFMA_PEAK_TF if args.dtype == "f32" else F16_MFMA_PEAK_TF
         roof = {"bound": "mfma", "kernel": plan["name"], "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                "frac": (achieved / peak) if achieved else None, "alg_flop_per_launch": alg, "traffic": None}
+                "frac": (achieved / peak) if achieved else None, "alg_flop_per_launch": alg}
+        roof["traffic"], roof["traffic_source"] = shape_traffic(args.dtype, M, K)
     roof["avg_launch_us"] = avg_us
     roof["probe"] = {"head_interval_us": head_us, "lin2_plus_lin3_interval_us": pair_us, "record_node_us": ovh_us, "steps_probed": n_probe,
                      "note": "HIP event-record nodes inside the timed batch graph, on the launch stream: one interval around the step head, "

@@ -60,6 +60,10 @@ typedef struct {
 } nd_config;
 #define ND_DTYPE_F32 0
 #define ND_DTYPE_F16 1
+/* nd_cond_config only: fp32 arithmetic as ND_DTYPE_F32 -- exact products, fp32 sums -- with the ViT's Linear layers on the bf16 matrix
+ * pipe (nd_gemm_split): their weights are handed over as frag32b3 images (nd_split_rows of the fp32 [out,in] weight, made once at
+ * load), embed_dim, mlp_hidden and in_chans*patch^2 must be multiples of 32.  The mapping MLPs and the attention run as in F32. */
+#define ND_DTYPE_F32_SPLIT 2
 
 /* Device pointers to ONE member's raw parameters, exactly the tensors of
  * ConditionalModel.state_dict() (key in the comment; shapes for config dims). */
@@ -196,18 +200,44 @@ int nd_gemm_bias_act(const float *x_dev, const void *w_dev, const float *bias_de
                      float *out_dev, int M, int K, int N, int act, int dtype, void *workspace_dev, size_t workspace_bytes,
                      void *stream);
 
-/* nn.LayerNorm(eps) over the last dim: x [rows, dim] -> out.  timm Block.norm1/norm2 (eps 1e-6). */
+/* The same Linear layers (timm 0.4.12 Attention.qkv / proj, Mlp.fc1 / fc2, PatchEmbed.proj; call sites
+ * classification_train_separately.py:337-346) on the bf16 matrix pipe WITH EXACT fp32 PRODUCTS: every fp32 operand value is held as
+ * its three exact bf16 pieces a = a1 + a2 + a3 (8 + 8 + 8 significand bits), the nine piece products of a pair are exact in fp32 and
+ * are accumulated in fp32 by v_mfma_f32_16x16x32_bf16 -- the reference's arithmetic (exact products, fp32 sums) in another summation
+ * order, at 9/16 of the matrix-pipe cycles of the f32-input MFMA.  Operands are "frag32b3" images (csrc/nd_b9.hpp): made ONCE by
+ * nd_split_rows (weights at load) or written directly by the producing operator (nd_layernorm_split, nd_gemm_split's out_split, ...).
+ *   nd_split_bytes(rows, K)   bytes of the image of a [rows, K] matrix (rows padded to 16; K % 32 == 0), 0 on a bad shape
+ *   nd_split_rows             x [rows, K] fp32 row-major -> image;   nd_join_rows: the inverse (exact), for tests
+ *   nd_gemm_split             out[M,N] = act(x . w^T + bias) (+ residual): x_split_dev image of [M,K], w_split_dev image of [N,K];
+ *                             out_dev fp32 [M,N] and / or out_split_dev = image of the result (N % 32 == 0) for the next layer; one of the
+ *                             two may be NULL.  workspace as nd_gemm_bias_act (>= nd_gemm_split_workspace_bytes, may be NULL). */
+size_t nd_split_bytes(int rows, int K);
+int nd_split_rows(const float *x_dev, void *out_split_dev, int rows, int K, void *stream);
+int nd_join_rows(const void *in_split_dev, float *x_dev, int rows, int K, void *stream);
+size_t nd_gemm_split_workspace_bytes(int M, int K, int N);
+int nd_gemm_split(const void *x_split_dev, const void *w_split_dev, const float *bias_dev, const float *residual_dev, float *out_dev,
+                  void *out_split_dev, int M, int K, int N, int act, void *workspace_dev, size_t workspace_bytes, void *stream);
+
+/* nn.LayerNorm(eps) over the last dim: x [rows, dim] -> out.  timm Block.norm1/norm2 (eps 1e-6).
+ * nd_layernorm_split: the same values written as the frag32b3 image of [rows, dim] (dim % 32 == 0; nd_split_bytes(rows, dim) bytes):
+ * the input of the nd_gemm_split that follows each LayerNorm of a ViT block. */
 int nd_layernorm(const float *x_dev, const float *gamma_dev, const float *beta_dev, float *out_dev,
                  int rows, int dim, float eps, void *stream);
+int nd_layernorm_split(const float *x_dev, const float *gamma_dev, const float *beta_dev, void *out_split_dev,
+                       int rows, int dim, float eps, void *stream);
 
 /* timm 0.4.12 Attention core: qkv [B, N, 3, heads, d] (the qkv Linear's output, unpermuted) ->
  * out [B, N, heads*d] = softmax(q k^T * d^-0.5) v, heads concatenated.  d must be 64.
  * dtype ND_DTYPE_F16 (fp16 mode): q, k, v and the normalised probabilities rounded to fp16, f16 MFMA, fp32 softmax/accumulate/out. */
 int nd_attention(const float *qkv_dev, float *out_dev, int B, int N, int heads, int d, int dtype, void *stream);
+/* The fp32 attention with its result written as the frag32b3 image of [B*N, heads*d] (the input of the proj nd_gemm_split). */
+int nd_attention_split(const float *qkv_dev, void *out_split_dev, int B, int N, int heads, int d, void *stream);
 
 /* PatchEmbed im2col: img [B, Cin, Himg, Wimg] NCHW -> cols [B * (Himg/p) * (Wimg/p), Cin*p*p] so that
  * Conv2d(k=p, s=p) becomes nd_gemm_bias_act with the conv weight viewed [embed, Cin*p*p]. */
 int nd_patchify(const float *img_dev, float *cols_dev, int B, int Cin, int Himg, int Wimg, int p, void *stream);
+/* The same im2col written as the frag32b3 image of its [B * (Himg/p) * (Wimg/p), Cin*p*p] result (Cin*p*p % 32 == 0). */
+int nd_patchify_split(const float *img_dev, void *cols_split_dev, int B, int Cin, int Himg, int Wimg, int p, void *stream);
 
 /* softmax over the last dim of [rows, C] (classification_train_separately.py:755-758). */
 int nd_softmax_rows(const float *x_dev, float *out_dev, int rows, int C, void *stream);
@@ -258,7 +288,8 @@ typedef struct {
 /* timm PatchEmbed.proj viewed [embed, in_chans*patch*patch] (+ bias); fp32, or fp16 in the fp16 mode. */
 typedef struct { const void *proj_w; const float *proj_b; } nd_patch_embed_weights;
 /* One timm Block: norm1, attn.qkv [3E,E], attn.proj [E,E], norm2, mlp.fc1 [4E,E], mlp.fc2 [E,4E]; Linear weights row-major
- * [out,in] (nn.Linear layout), fp32 or fp16 per operand_dtype; everything else fp32. */
+ * [out,in] (nn.Linear layout) in fp32 (ND_DTYPE_F32) or fp16 (ND_DTYPE_F16), or frag32b3 images of them (ND_DTYPE_F32_SPLIT: nd_split_rows;
+ * the same holds for nd_patch_embed_weights.proj_w viewed [embed, in_chans*patch^2]); everything else fp32. */
 typedef struct {
     const float *norm1_w, *norm1_b;
     const void *qkv_w;  const float *qkv_b;

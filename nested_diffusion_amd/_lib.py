@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("ND_LIB_PATH") or os.path.join(HERE, "libnd_hip.so")  
 
 ND_ACT_NONE, ND_ACT_SOFTPLUS, ND_ACT_RELU, ND_ACT_GELU = 0, 1, 2, 3
 ND_DTYPE_F32, ND_DTYPE_F16 = 0, 1
+ND_DTYPE_F32_SPLIT = 2      # nd_cond_config only: fp32 arithmetic, ViT Linear layers on the bf16 pipe (weights as frag32b3 images)
 
 
 def dtype_code(dtype) -> int:
@@ -128,9 +129,17 @@ SIGNATURES = {
     "nd_step_plan": (_i, [_i, _i, _i, _i, C.POINTER(_i)]),
     "nd_gemm_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "nd_gemm_bias_act": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "nd_split_bytes": (_sz, [_i, _i]),
+    "nd_split_rows": (_i, [_vp, _vp, _i, _i, _vp]),
+    "nd_join_rows": (_i, [_vp, _vp, _i, _i, _vp]),
+    "nd_gemm_split_workspace_bytes": (_sz, [_i, _i, _i]),
+    "nd_gemm_split": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
     "nd_layernorm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
+    "nd_layernorm_split": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "nd_attention": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "nd_attention_split": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "nd_patchify": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "nd_patchify_split": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "nd_softmax_rows": (_i, [_vp, _vp, _i, _i, _vp]),
     "nd_aggregate": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
     "nd_sample_stats": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _f, _vp]),

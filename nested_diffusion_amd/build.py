@@ -14,11 +14,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libnd_hip.so")
 SOURCES = ["nd_sampler.hip", "nd_ops.hip", "nd_vit.hip", "nd_image.hip", "nd_cond_gemm.hip", "nd_attention.hip", "nd_gemm_f32.hip",
-           "nd_conditioner.hip", "nd_rng.hip"]
+           "nd_conditioner.hip", "nd_rng.hip", "nd_gemm_b9.hip"]
 # per-file flags: the large-M tile kernel keeps its accumulators in VGPRs (see nd_cond_gemm.hpp)
 EXTRA_FLAGS = {"nd_cond_gemm.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "nd_attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
-               "nd_gemm_f32.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
-HEADERS = [os.path.join(CSRC, "nd_common.hpp"), os.path.join(CSRC, "nd_cond_gemm.hpp"), os.path.join(CSRC, "nd_rng.hpp"), os.path.join(os.path.dirname(HERE), "include", "nested_diffusion.h")]
+               "nd_gemm_f32.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "nd_gemm_b9.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+HEADERS = [os.path.join(CSRC, "nd_common.hpp"), os.path.join(CSRC, "nd_cond_gemm.hpp"), os.path.join(CSRC, "nd_rng.hpp"), os.path.join(CSRC, "nd_b9.hpp"), os.path.join(os.path.dirname(HERE), "include", "nested_diffusion.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-Werror=inline-asm"]
 
 

@@ -3,6 +3,7 @@
 // (nested_diffusion_amd/build.py): the score accumulators are consumed by the softmax (VALU) and fed back as MFMA operands, so
 // keeping them in AGPRs costs a v_accvgpr move per value each way.
 #include "nd_common.hpp"
+#include "nd_b9.hpp"
 
 // RING form (the default fp32 kernel).  A workgroup is FOUR waves -- one per SIMD -- owning up to four 16-row query fragments
 // of one (image, head): ceil(NF/4) workgroups per head (NF = 13 at N = 196: 4 + 3 + 3 + 3 fragments), 1536 workgroups at
@@ -52,7 +53,7 @@ extern "C" int nd_debug_set_att_stamps(void* p) { return hipMemcpyToSymbol(HIP_S
 #endif
 template <int NF, int NT>
 __global__ __launch_bounds__(256) void k_attention_ring(const float* __restrict__ qkv, float* __restrict__ out, int B, int N, int heads,
-                                                        int QG) {
+                                                        int QG, int split_out) {
     constexpr int TF = (NF + NT - 1) / NT;                // key fragments per tile (the last tile may hold fewer)
     constexpr int SLOT = TF * 16 * 64;                    // floats per slot
     __shared__ __attribute__((aligned(16))) float smem[2 * SLOT];
@@ -230,25 +231,32 @@ __global__ __launch_bounds__(256) void k_attention_ring(const float* __restrict_
     // o[e][r'] = O[q = l&15][d = 4*(4g + r') + e]  ->  float4 over e at d0 = 16g + 4r'
     const int qo = qf * 16 + li;
     if (active && qo < N) {
-        float* op = out + ((size_t)b * N + qo) * Cm + (size_t)hd * 64 + 16 * g;
+        if (split_out) {
+            // `out` is the frag32b3 image of [B*N, heads*64] (csrc/nd_b9.hpp): the input form of the proj Linear that follows
 #pragma unroll
-        for (int r = 0; r < 4; ++r) *reinterpret_cast<float4*>(op + 4 * r) = make_float4(o[0][r], o[1][r], o[2][r], o[3][r]);
+            for (int r = 0; r < 4; ++r)
+                nd_b9_store4(reinterpret_cast<bf16x8*>(out), Cm >> 5, b * N + qo, hd * 64 + 16 * g + 4 * r, o[0][r], o[1][r], o[2][r], o[3][r]);
+        } else {
+            float* op = out + ((size_t)b * N + qo) * Cm + (size_t)hd * 64 + 16 * g;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) *reinterpret_cast<float4*>(op + 4 * r) = make_float4(o[0][r], o[1][r], o[2][r], o[3][r]);
+        }
     }
     ATT_STAMP(13)
 }
 
 template <int NF>
-static hipError_t launch_attention_ring(const float* qkv, float* out, int B, int N, int heads, hipStream_t st) {
+static hipError_t launch_attention_ring(const float* qkv, float* out, int B, int N, int heads, int split_out, hipStream_t st) {
     // tiles per operand: 3 where that leaves whole tiles to stream (NF >= 6), else 2 / 1
     constexpr int NT = NF >= 6 ? 3 : (NF >= 2 ? 2 : 1);
     const int QG = (NF + 3) / 4;
-    hipLaunchKernelGGL((k_attention_ring<NF, NT>), dim3(B * heads * QG), dim3(256), 0, st, qkv, out, B, N, heads, QG);
+    hipLaunchKernelGGL((k_attention_ring<NF, NT>), dim3(B * heads * QG), dim3(256), 0, st, qkv, out, B, N, heads, QG, split_out);
     return hipGetLastError();
 }
 
-hipError_t nd_launch_attention_ring(const float* qkv, float* out, int B, int N, int heads, hipStream_t st) {
+hipError_t nd_launch_attention_ring(const float* qkv, float* out, int B, int N, int heads, int split_out, hipStream_t st) {
     switch ((N + 15) / 16) {
-#define AR_CASE(NFV) case NFV: return launch_attention_ring<NFV>(qkv, out, B, N, heads, st);
+#define AR_CASE(NFV) case NFV: return launch_attention_ring<NFV>(qkv, out, B, N, heads, split_out, st);
         AR_CASE(1) AR_CASE(2) AR_CASE(3) AR_CASE(4) AR_CASE(5) AR_CASE(6) AR_CASE(7) AR_CASE(8)
         AR_CASE(9) AR_CASE(10) AR_CASE(11) AR_CASE(12) AR_CASE(13) AR_CASE(14) AR_CASE(15) AR_CASE(16)
 #undef AR_CASE

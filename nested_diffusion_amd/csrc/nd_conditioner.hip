@@ -35,6 +35,8 @@ struct nd_cond_s {
     size_t ws_bytes = 0;
     // carved activations
     float *cols = nullptr, *tok = nullptr, *mid_tok = nullptr, *h = nullptr, *qkv = nullptr, *att = nullptr, *fc1 = nullptr;
+    // ND_DTYPE_F32_SPLIT: frag32b3 images of the GEMM inputs (csrc/nd_b9.hpp): xs = the current [R, kpe | E] input, fc1s = GELU(fc1)
+    void *xs = nullptr, *fc1s = nullptr;
     float* m[3] = {nullptr, nullptr, nullptr};
     void *gemm_ws = nullptr, *lin_ws = nullptr;
     size_t gemm_ws_bytes = 0, lin_ws_bytes = 0;
@@ -47,14 +49,16 @@ static int check_cfg(const nd_cond_config* c) {
     if (c->patch < 4 || (c->patch % 4) || c->img_size < c->patch || (c->img_size % c->patch) || c->in_chans < 1)
         return nd_set_err(ND_ERR_ARG, "patch must be a multiple of 4 dividing img_size");
     if (c->num_heads < 1 || c->embed_dim != 64 * c->num_heads) return nd_set_err(ND_ERR_ARG, "embed_dim must be 64 * num_heads");
-    if (c->operand_dtype != ND_DTYPE_F32 && c->operand_dtype != ND_DTYPE_F16) return nd_set_err(ND_ERR_ARG, "unknown operand_dtype");
-    const int km = c->operand_dtype == ND_DTYPE_F16 ? 32 : 16;
+    if (c->operand_dtype != ND_DTYPE_F32 && c->operand_dtype != ND_DTYPE_F16 && c->operand_dtype != ND_DTYPE_F32_SPLIT)
+        return nd_set_err(ND_ERR_ARG, "unknown operand_dtype");
+    const int km = c->operand_dtype == ND_DTYPE_F32 ? 16 : 32;
     const int kpe = c->in_chans * c->patch * c->patch;
     if ((c->embed_dim % km) || (c->mlp_hidden % km) || c->mlp_hidden < km || (kpe % km))
         return nd_set_err(ND_ERR_ARG, "embed_dim, mlp_hidden and in_chans*patch^2 must be multiples of %d", km);
     if (c->n_mlps < 1 || c->n_blocks < c->n_mlps) return nd_set_err(ND_ERR_ARG, "need 1 <= n_mlps <= n_blocks");
+    const int kw = c->operand_dtype == ND_DTYPE_F16 ? 32 : 16;      // the mapping MLPs stream fp32 (F32, F32_SPLIT) or fp16 weights
     for (int i = 0; i < 3; ++i)
-        if (c->mlp_widths[i] < km || (c->mlp_widths[i] % km)) return nd_set_err(ND_ERR_ARG, "mlp_widths must be multiples of %d", km);
+        if (c->mlp_widths[i] < kw || (c->mlp_widths[i] % kw)) return nd_set_err(ND_ERR_ARG, "mlp_widths must be multiples of %d", kw);
     if (c->num_classes < 1 || c->max_batch < 1) return nd_set_err(ND_ERR_ARG, "num_classes / max_batch invalid");
     const int ntok = (c->img_size / c->patch) * (c->img_size / c->patch);
     if (c->max_tokens < ntok || c->max_tokens > 256) return nd_set_err(ND_ERR_ARG, "max_tokens must be in [%d, 256]", ntok);
@@ -78,12 +82,28 @@ static void carve(nd_cond_s* c, char* base, size_t* total) {
     c->h = (float*)take(R * E * 4);
     c->qkv = (float*)take(R * 3 * E * 4);
     c->att = (float*)take(R * E * 4);
-    c->fc1 = (float*)take(R * Hd * 4);
+    const bool split = g.operand_dtype == ND_DTYPE_F32_SPLIT;
+    const int dt = split ? ND_DTYPE_F32 : g.operand_dtype;       // what the attention kernel and the mapping MLPs run in
+    if (split) {
+        c->fc1 = nullptr;
+        c->xs = take(nd_split_bytes((int)R, (int)(kpe > E ? kpe : E)));
+        c->fc1s = take(nd_split_bytes((int)R, (int)Hd));
+    } else {
+        c->fc1 = (float*)take(R * Hd * 4);
+        c->xs = c->fc1s = nullptr;
+    }
     for (int i = 0; i < 3; ++i) c->m[i] = (float*)take(((B + 15) / 16 * 16) * (size_t)g.mlp_widths[i] * 4);   // packed: whole 16-row tiles
-    const int dt = g.operand_dtype;
     size_t gw = 0;
     const int rows[2] = {(int)(B * ntok), (int)R};
     for (int r : rows) {
+        if (split) {
+            gw = zmax(gw, nd_gemm_split_workspace_bytes(r, (int)kpe, (int)E));
+            gw = zmax(gw, nd_gemm_split_workspace_bytes(r, (int)E, (int)(3 * E)));
+            gw = zmax(gw, nd_gemm_split_workspace_bytes(r, (int)E, (int)E));
+            gw = zmax(gw, nd_gemm_split_workspace_bytes(r, (int)E, (int)Hd));
+            gw = zmax(gw, nd_gemm_split_workspace_bytes(r, (int)Hd, (int)E));
+            continue;
+        }
         gw = zmax(gw, nd_gemm_workspace_bytes(r, (int)kpe, (int)E, dt));
         gw = zmax(gw, nd_gemm_workspace_bytes(r, (int)E, (int)(3 * E), dt));
         gw = zmax(gw, nd_gemm_workspace_bytes(r, (int)E, (int)E, dt));
@@ -202,6 +222,18 @@ static int vit_block(nd_cond_s* c, int block, const float* tin, float* tout, int
     const nd_cond_config& g = c->cfg;
     const nd_vit_block_weights& w = c->blocks[block];
     const int E = g.embed_dim, Hd = g.mlp_hidden, R = B * N, dt = g.operand_dtype;
+    if (dt == ND_DTYPE_F32_SPLIT) {
+        // the same block with the four Linear layers on the bf16 matrix pipe, exact fp32 products (csrc/nd_b9.hpp): the weights are
+        // frag32b3 images, every GEMM input is written as one by its producer (LayerNorm, attention and the fc1 epilogue)
+        ND_TRY(nd_layernorm_split(tin, w.norm1_w, w.norm1_b, c->xs, R, E, g.ln_eps, st));
+        ND_TRY(nd_gemm_split(c->xs, w.qkv_w, w.qkv_b, nullptr, c->qkv, nullptr, R, E, 3 * E, ND_ACT_NONE, c->gemm_ws, c->gemm_ws_bytes, st));
+        ND_TRY(nd_attention_split(c->qkv, c->xs, B, N, g.num_heads, 64, st));
+        ND_TRY(nd_gemm_split(c->xs, w.proj_w, w.proj_b, tin, c->mid_tok, nullptr, R, E, E, ND_ACT_NONE, c->gemm_ws, c->gemm_ws_bytes, st));
+        ND_TRY(nd_layernorm_split(c->mid_tok, w.norm2_w, w.norm2_b, c->xs, R, E, g.ln_eps, st));
+        ND_TRY(nd_gemm_split(c->xs, w.fc1_w, w.fc1_b, nullptr, nullptr, c->fc1s, R, E, Hd, ND_ACT_GELU, c->gemm_ws, c->gemm_ws_bytes, st));
+        ND_TRY(nd_gemm_split(c->fc1s, w.fc2_w, w.fc2_b, c->mid_tok, tout, nullptr, R, Hd, E, ND_ACT_NONE, c->gemm_ws, c->gemm_ws_bytes, st));
+        return ND_OK;
+    }
     // x = x + attn(norm1(x))
     ND_TRY(nd_layernorm(tin, w.norm1_w, w.norm1_b, c->h, R, E, g.ln_eps, st));
     ND_TRY(nd_gemm_bias_act(c->h, w.qkv_w, w.qkv_b, nullptr, c->qkv, R, E, 3 * E, ND_ACT_NONE, dt, c->gemm_ws, c->gemm_ws_bytes, st));
@@ -235,12 +267,20 @@ int nd_guiding_prediction_first(nd_cond c, const float* images, float* logits_ou
     if (!c->have_pe) return nd_set_err(ND_ERR_STATE, "patch embedding not set");
     for (int i = 0; i < n_used; ++i)
         if (!c->have_block[i] || !c->have_mlp[i]) return nd_set_err(ND_ERR_STATE, "block / mlp %d not set", i);
-    const int E = g.embed_dim, gs = g.img_size / g.patch, ntok = gs * gs, kpe = g.in_chans * g.patch * g.patch, dt = g.operand_dtype;
+    const int E = g.embed_dim, gs = g.img_size / g.patch, ntok = gs * gs, kpe = g.in_chans * g.patch * g.patch;
+    const bool split = g.operand_dtype == ND_DTYPE_F32_SPLIT;
+    const int dt = split ? ND_DTYPE_F32 : g.operand_dtype;
     const int C = g.num_classes;
     // tmp = vit.patch_embed(x); vit.pos_drop is the identity in eval; no cls token, no pos_embed (:337-338, quirk Q3)
-    ND_TRY(nd_patchify(images, c->cols, B, g.in_chans, g.img_size, g.img_size, g.patch, stream));
-    ND_TRY(nd_gemm_bias_act(c->cols, c->pe.proj_w, c->pe.proj_b, nullptr, c->tok, B * ntok, kpe, E, ND_ACT_NONE, dt, c->gemm_ws,
-                            c->gemm_ws_bytes, stream));
+    if (split) {
+        ND_TRY(nd_patchify_split(images, c->xs, B, g.in_chans, g.img_size, g.img_size, g.patch, stream));
+        ND_TRY(nd_gemm_split(c->xs, c->pe.proj_w, c->pe.proj_b, nullptr, c->tok, nullptr, B * ntok, kpe, E, ND_ACT_NONE, c->gemm_ws, c->gemm_ws_bytes,
+                             stream));
+    } else {
+        ND_TRY(nd_patchify(images, c->cols, B, g.in_chans, g.img_size, g.img_size, g.patch, stream));
+        ND_TRY(nd_gemm_bias_act(c->cols, c->pe.proj_w, c->pe.proj_b, nullptr, c->tok, B * ntok, kpe, E, ND_ACT_NONE, dt, c->gemm_ws,
+                                c->gemm_ws_bytes, stream));
+    }
     const int dims[5] = {ntok * E, g.mlp_widths[0], g.mlp_widths[1], g.mlp_widths[2], C};
     for (int i = 0; i < n_used; ++i) {
         // member i's prefix blocks[0..i] reuse member i-1's tokens (:339-340 recomputes them from patch_embed: same values)

@@ -1,0 +1,286 @@
+// nd_gemm_b9.hip -- fp32 Linear layers of the ViT blocks on the bf16 matrix pipe with exact products (design: nd_b9.hpp):
+//     out[m,n] = act(sum_k x[m,k] w[n,k] + bias[n]) + res[m,n]
+// (timm 0.4.12 Attention.qkv / proj, Mlp.fc1 / fc2, PatchEmbed.proj as a GEMM over im2col rows; call sites
+// classification_train_separately.py:337-346), x and w handed over as frag32b3 images (three exact bf16 pieces per fp32 value).
+// gfx950 only; built with -mllvm -amdgpu-mfma-vgpr-form (nested_diffusion_amd/build.py).
+//
+// Two workgroup shapes over the same main loop, picked per GEMM by nd_b9_plan:
+//   * 4 waves, tile 128 (w rows) x 64 (x rows), 72 KiB of LDS: two workgroups per CU, each wave 64 x 32.  Best at K = 768 (qkv, fc1,
+//     proj, patch embedding): two independent barriers per CU, and a last round that is half empty runs its lone workgroups at
+//     almost twice the speed (they have the SIMDs to themselves), so such tails are left whole.
+//   * 8 waves, tile 128 x 128, 96 KiB: one workgroup per CU, the same 64 x 32 per wave; a third fewer bytes staged per MFMA.  Best at
+//     K >= 2048 (fc2).
+// tiles % slots != 0 leaves the last round partly empty: where that costs more than it saves, the remainder tiles are cut into
+// `split` k-slabs, raw accumulators to the caller's workspace, finished by k_b9_fixup (slabs added in order: reproducible).
+// Epilogue (kernel and fixup alike): bias, activation, residual, then fp32 row-major store and / or a frag32b3 store of the result
+// for the GEMM that consumes it (fc1 -> fc2), so that no separate pass ever splits an activation.
+#include "nd_b9.hpp"
+#include "../../include/nested_diffusion.h"
+
+int nd_set_err(int code, const char* fmt, ...);
+#define HIP_CHECK(expr)                                                                              \
+    do {                                                                                             \
+        hipError_t _e = (expr);                                                                      \
+        if (_e != hipSuccess)                                                                        \
+            return nd_set_err(ND_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+struct B9Epilogue {
+    const float* bias;      // [N] or null
+    const float* res;       // [M][N] or null (added after the activation)
+    float* out;             // [M][N] fp32 row-major or null
+    bf16x8* out_split;      // frag32b3 image of [M][N] (N % 32 == 0) or null
+    int act;
+};
+
+// lane's 4 consecutive output columns n0 .. n0+3 of row m
+__device__ __forceinline__ void b9_epilogue(const B9Epilogue& e, f32x4 a, int m, int n0, int M, int N) {
+    if (m >= M || n0 >= N) return;
+    float v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int nn = min(n0 + r, N - 1);
+        float t = a[r] + (e.bias ? e.bias[nn] : 0.f);
+        t = nd_act(t, e.act);
+        if (e.res && n0 + r < N) t += e.res[(size_t)m * N + n0 + r];
+        v[r] = t;
+    }
+    if (e.out) {
+        float* p = e.out + (size_t)m * N + n0;
+        if (n0 + 3 < N && (N & 3) == 0) *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+        else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (n0 + r < N) p[r] = v[r];
+        }
+    }
+    if (e.out_split) nd_b9_store4(e.out_split, N >> 5, m, n0, v[0], v[1], v[2], v[3]);     // N % 32 == 0 (checked on the host)
+}
+
+template <int FA, int FB, int WN, int WM, int NS>
+__global__ __launch_bounds__(64 * WN * WM) void k_gemm_b9(const bf16x8* __restrict__ xs, const bf16x8* __restrict__ ws, B9Epilogue ep, int M, int K,
+                                                          int N, int n_full, int split, f32x4* __restrict__ part) {
+    constexpr int NW = WN * WM, NPC = (WN * FA + WM * FB) * 3, NP = (NPC + NW - 1) / NW;
+    extern __shared__ __attribute__((aligned(16))) bf16x8 lds[];     // [NS][WN*FA + WM*FB][3][64]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave / WM, wm = wave % WM;
+    const int TN = (N + WN * FA * 16 - 1) / (WN * FA * 16);
+    int bid = blockIdx.x, slab = -1, rem_index = 0;
+    if (bid < n_full) {
+        // blocks b and b + 8 share an XCD (round-robin dispatch): XCD x takes a contiguous run of tiles, n fastest, so the workgroups
+        // that share an L2 share an x panel
+        const int q = n_full / 8, r = n_full % 8, xcd = bid % 8, loc = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    } else {
+        const int j = bid - n_full;
+        rem_index = j / split; slab = j % split; bid = n_full + rem_index;
+    }
+    const int tm = bid / TN, tn = bid - tm * TN;
+    const int nkb = K >> 5, nfr = (N + 15) >> 4, mfr = (M + 15) >> 4;
+    const int c0 = slab < 0 ? 0 : (int)((long)slab * nkb / split), c1 = slab < 0 ? nkb : (int)((long)(slab + 1) * nkb / split);
+    const bf16x8* src[NP];
+#pragma unroll
+    for (int u = 0; u < NP; ++u) {
+        const int e = min(wave * NP + u, NPC - 1), f = e / 3, pl = e % 3;
+        // fragment indices past the matrix edge are clamped (their products are never stored)
+        const bf16x8* base = f < WN * FA ? ws + ((size_t)min(tn * WN * FA + f, nfr - 1) * nkb + c0) * B9_BLOCK_UNITS
+                                         : xs + ((size_t)min(tm * WM * FB + f - WN * FA, mfr - 1) * nkb + c0) * B9_BLOCK_UNITS;
+        src[u] = base + pl * 64 + lane;
+    }
+    f32x4 acc[FA][FB];
+#pragma unroll
+    for (int i = 0; i < FA; ++i)
+#pragma unroll
+        for (int j = 0; j < FB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    b9_mainloop<FA, FB, WN, WM, NS>(acc, src, lds, c1 - c0, wave, wn, wm, lane);
+    if (slab >= 0) {     // raw accumulators of a k-slab: [remainder tile][slab][wave][fragment][lane], one coalesced 1 KiB store per fragment
+        f32x4* pt = part + (((size_t)rem_index * split + slab) * NW + wave) * (FA * FB) * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < FA; ++i)
+#pragma unroll
+            for (int j = 0; j < FB; ++j) *(__attribute__((address_space(1))) f32x4*)(pt + (i * FB + j) * 64) = acc[i][j];
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < FA; ++i)
+#pragma unroll
+        for (int j = 0; j < FB; ++j)
+            b9_epilogue(ep, acc[i][j], ((tm * WM + wm) * FB + j) * 16 + (lane & 15), ((tn * WN + wn) * FA + i) * 16 + 4 * (lane >> 4), M, N);
+}
+
+// Finishes the k-split tiles: one wave per (remainder tile, wave sub-tile, FRAGMENT) -- a chain of `split` dependent 1 KiB reads per
+// wave, so the launch wants many short waves (with one wave per 8 fragments it took 18-24 us, more than the k-split saved at
+// K = 768) -- slabs added in slab order: reproducible.  4 fragments per 256-thread workgroup.
+template <int FA, int FB, int WN, int WM>
+__global__ __launch_bounds__(256) void k_b9_fixup(const f32x4* __restrict__ part, B9Epilogue ep, int M, int N, int n_full, int split) {
+    constexpr int NW = WN * WM, NF = FA * FB;
+    const int lane = threadIdx.x & 63;
+    const int fid = blockIdx.x * 4 + (threadIdx.x >> 6);            // (remainder tile, wave, fragment)
+    const int f = fid % NF, wave = (fid / NF) % NW, ri = fid / (NF * NW);
+    const int i = f / FB, j = f - i * FB;
+    const int wn = wave / WM, wm = wave % WM;
+    const int TN = (N + WN * FA * 16 - 1) / (WN * FA * 16);
+    const int bid = n_full + ri, tm = bid / TN, tn = bid - tm * TN;
+    const f32x4* p = part + (((size_t)ri * split * NW + wave) * NF + f) * 64 + lane;
+    f32x4 a = *(const __attribute__((address_space(1))) f32x4*)p;
+    for (int k = 1; k < split; ++k) a += *(const __attribute__((address_space(1))) f32x4*)(p + (size_t)k * NW * NF * 64);
+    b9_epilogue(ep, a, ((tm * WM + wm) * FB + j) * 16 + (lane & 15), ((tn * WN + wn) * FA + i) * 16 + 4 * (lane >> 4), M, N);
+}
+
+// x [R][K] fp32 row-major -> frag32b3.  One wave per (16 rows x 32 k) block: a lane reads 32 contiguous bytes of its row and writes
+// 16 bytes into each plane (three coalesced 1 KiB stores).  Rows R .. Rpad-1 of the last block are written as zeros.
+__global__ __launch_bounds__(256) void k_b9_split_rows(const float* __restrict__ x, bf16x8* __restrict__ out, int R, int K) {
+    const int lane = threadIdx.x & 63;
+    const long blk = ((long)blockIdx.x * 256 + threadIdx.x) >> 6;
+    const int nkb = K >> 5;
+    if (blk >= (long)((R + 15) >> 4) * nkb) return;
+    const int rb = (int)(blk / nkb), kb = (int)(blk - (long)rb * nkb);
+    const int row = rb * 16 + (lane & 15), k0 = kb * 32 + 8 * (lane >> 4);
+    float v[8];
+    if (row < R) {
+        const float4 u0 = *reinterpret_cast<const float4*>(x + (size_t)row * K + k0), u1 = *reinterpret_cast<const float4*>(x + (size_t)row * K + k0 + 4);
+        v[0] = u0.x; v[1] = u0.y; v[2] = u0.z; v[3] = u0.w; v[4] = u1.x; v[5] = u1.y; v[6] = u1.z; v[7] = u1.w;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    }
+    bf16x8 h1, h2, h3;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        __bf16 a, b, c;
+        nd_b9_split(v[e], a, b, c);
+        h1[e] = a; h2[e] = b; h3[e] = c;
+    }
+    out[(blk * 3 + 0) * 64 + lane] = h1;
+    out[(blk * 3 + 1) * 64 + lane] = h2;
+    out[(blk * 3 + 2) * 64 + lane] = h3;
+}
+
+// frag32b3 -> fp32 row-major (sum of the three pieces; exact): tests and debugging
+__global__ __launch_bounds__(256) void k_b9_join_rows(const bf16x8* __restrict__ in, float* __restrict__ x, int R, int K) {
+    const int lane = threadIdx.x & 63;
+    const long blk = ((long)blockIdx.x * 256 + threadIdx.x) >> 6;
+    const int nkb = K >> 5;
+    if (blk >= (long)((R + 15) >> 4) * nkb) return;
+    const int rb = (int)(blk / nkb), kb = (int)(blk - (long)rb * nkb);
+    const int row = rb * 16 + (lane & 15), k0 = kb * 32 + 8 * (lane >> 4);
+    if (row >= R) return;
+    const bf16x8 h1 = in[(blk * 3 + 0) * 64 + lane], h2 = in[(blk * 3 + 1) * 64 + lane], h3 = in[(blk * 3 + 2) * 64 + lane];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[(size_t)row * K + k0 + e] = ((float)h1[e] + (float)h2[e]) + (float)h3[e];
+}
+
+// ---- launch plan -----------------------------------------------------------------------------------------------------------------
+struct B9Plan { int wide; int tiles, n_full, rem, split, slots; size_t ws_bytes, lds_bytes; };
+#define B9_FA 4
+#define B9_FB 2
+#define B9_NS 2
+
+static B9Plan nd_b9_plan(int M, int K, int N) {
+    B9Plan p{};
+    p.wide = K >= 2048 ? 1 : 0;                                    // 8 waves, 128 x 128, one workgroup per CU
+    const int BM = (p.wide ? 4 : 2) * B9_FB * 16, BN = 2 * B9_FA * 16;
+    p.tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    const int ncu = nd_num_cus();
+    p.slots = ncu * (p.wide ? 1 : 2);
+    p.lds_bytes = (size_t)B9_NS * (2 * B9_FA + (p.wide ? 4 : 2) * B9_FB) * 3 * 1024;
+    p.n_full = p.tiles; p.rem = 0; p.split = 1;
+    const int rem = p.tiles % p.slots, nkb = K >> 5;
+    if (rem > 0 && p.tiles > p.slots) {
+        // Cost of the last round in microseconds (measured per K-step and workgroup at full residency: 1.3 us for the two-per-CU
+        // shape, 1.4 us for the wide one; ~4 us of prologue + epilogue per workgroup).  A workgroup that is alone on its CU in the
+        // two-per-CU shape has the SIMDs to itself and runs ~0.6 of the time.  A k-split adds the fixup launch: ~5 us + the slabs
+        // written and read back at ~3 TB/s.
+        const double t_step = p.wide ? 1.4 : 1.3;
+        const double lone = (!p.wide && rem <= ncu) ? 0.6 : 1.0;
+        double best = lone * (nkb * t_step + 4.0);
+        const int cand[] = {2, 3, 4, 6, 8};
+        for (int s : cand) {
+            if (nkb / s < 4) continue;
+            const long slabs = (long)rem * s;
+            const double rounds = (double)((slabs + p.slots - 1) / p.slots);
+            const double alone = (!p.wide && slabs <= ncu) ? 0.6 : 1.0;
+            const double t = rounds * alone * ((double)nkb / s * t_step + 5.0) + 5.0 + (double)slabs * BM * BN * 4.0 * 2.0 / 3.0e6;
+            if (t < best - 1e-9) { best = t; p.split = s; }
+        }
+        if (p.split > 1) { p.rem = rem; p.n_full = p.tiles - rem; }
+    }
+    p.ws_bytes = p.split > 1 ? (size_t)p.rem * p.split * BM * BN * sizeof(float) : 0;
+    return p;
+}
+
+extern "C" size_t nd_split_bytes(int rows, int K) {
+    if (rows < 1 || K < 32 || (K % 32)) return 0;
+    return nd_b9_bytes(rows, K);
+}
+
+extern "C" int nd_split_rows(const float* x_dev, void* out_dev, int rows, int K, void* stream) {
+    if (!x_dev || !out_dev) return nd_set_err(ND_ERR_ARG, "NULL tensor");
+    if (rows < 1 || K < 32 || (K % 32)) return nd_set_err(ND_ERR_ARG, "need rows >= 1 and K a positive multiple of 32 (K=%d)", K);
+    if (((uintptr_t)x_dev | (uintptr_t)out_dev) & 15) return nd_set_err(ND_ERR_ARG, "tensors must be 16-byte aligned");
+    const long nb = (long)((rows + 15) / 16) * (K / 32);
+    hipLaunchKernelGGL(k_b9_split_rows, dim3((unsigned)((nb * 64 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x_dev, (bf16x8*)out_dev, rows, K);
+    HIP_CHECK(hipGetLastError());
+    return ND_OK;
+}
+
+extern "C" int nd_join_rows(const void* in_dev, float* x_dev, int rows, int K, void* stream) {
+    if (!x_dev || !in_dev) return nd_set_err(ND_ERR_ARG, "NULL tensor");
+    if (rows < 1 || K < 32 || (K % 32)) return nd_set_err(ND_ERR_ARG, "need rows >= 1 and K a positive multiple of 32 (K=%d)", K);
+    const long nb = (long)((rows + 15) / 16) * (K / 32);
+    hipLaunchKernelGGL(k_b9_join_rows, dim3((unsigned)((nb * 64 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const bf16x8*)in_dev, x_dev, rows, K);
+    HIP_CHECK(hipGetLastError());
+    return ND_OK;
+}
+
+extern "C" size_t nd_gemm_split_workspace_bytes(int M, int K, int N) {
+    if (M < 1 || N < 1 || K < 32 || (K % 32)) return 0;
+    return nd_b9_plan(M, K, N).ws_bytes;
+}
+
+// hipFuncSetAttribute is per device: remember which devices have had it (one bit each)
+static hipError_t b9_allow_lds(const void* fn, size_t bytes, unsigned long long* done_mask) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 64 && ((*done_mask >> dev) & 1ull)) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess && dev < 64) *done_mask |= 1ull << dev;
+    return e;
+}
+
+extern "C" int nd_gemm_split(const void* x_split, const void* w_split, const float* bias, const float* res, float* out, void* out_split,
+                             int M, int K, int N, int act, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!x_split || !w_split || (!out && !out_split)) return nd_set_err(ND_ERR_ARG, "NULL tensor");
+    if (M < 1 || N < 1 || K < 32 || (K % 32)) return nd_set_err(ND_ERR_ARG, "need M,N >= 1 and K a positive multiple of 32 (K=%d)", K);
+    if (out_split && (N % 32)) return nd_set_err(ND_ERR_ARG, "a split (frag32b3) output needs N %% 32 == 0 (N=%d)", N);
+    if (act < 0 || act > 3) return nd_set_err(ND_ERR_ARG, "unknown activation %d", act);
+    if (((uintptr_t)x_split | (uintptr_t)w_split | (uintptr_t)out | (uintptr_t)out_split | (uintptr_t)res) & 15)
+        return nd_set_err(ND_ERR_ARG, "tensors must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    B9Plan p = nd_b9_plan(M, K, N);
+    if (p.split > 1 && (!workspace || workspace_bytes < p.ws_bytes || ((uintptr_t)workspace & 15))) {
+        // no (or too small / misaligned) workspace: every tile whole -- same results up to summation order, longer tail
+        p.n_full = p.tiles; p.rem = 0; p.split = 1;
+    }
+    B9Epilogue ep{bias, res, out, (bf16x8*)out_split, act};
+    const unsigned grid = (unsigned)(p.n_full + p.rem * p.split);
+    static unsigned long long done_n = 0, done_w = 0;
+    if (p.wide) {
+        auto kern = k_gemm_b9<B9_FA, B9_FB, 2, 4, B9_NS>;
+        HIP_CHECK(b9_allow_lds((const void*)kern, p.lds_bytes, &done_w));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), p.lds_bytes, st, (const bf16x8*)x_split, (const bf16x8*)w_split, ep, M, K, N, p.n_full, p.split,
+                           (f32x4*)workspace);
+        HIP_CHECK(hipGetLastError());
+        if (p.rem > 0) hipLaunchKernelGGL((k_b9_fixup<B9_FA, B9_FB, 2, 4>), dim3(p.rem * 8 * B9_FA * B9_FB / 4), dim3(256), 0, st, (const f32x4*)workspace, ep, M, N, p.n_full, p.split);
+    } else {
+        auto kern = k_gemm_b9<B9_FA, B9_FB, 2, 2, B9_NS>;
+        HIP_CHECK(b9_allow_lds((const void*)kern, p.lds_bytes, &done_n));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), p.lds_bytes, st, (const bf16x8*)x_split, (const bf16x8*)w_split, ep, M, K, N, p.n_full, p.split,
+                           (f32x4*)workspace);
+        HIP_CHECK(hipGetLastError());
+        if (p.rem > 0) hipLaunchKernelGGL((k_b9_fixup<B9_FA, B9_FB, 2, 2>), dim3(p.rem * 4 * B9_FA * B9_FB / 4), dim3(256), 0, st, (const f32x4*)workspace, ep, M, N, p.n_full, p.split);
+    }
+    HIP_CHECK(hipGetLastError());
+    return ND_OK;
+}

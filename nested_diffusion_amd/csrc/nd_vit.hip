@@ -2,6 +2,7 @@
 // semantics; call sites classification_train_separately.py:337-340).  gfx950 only, fp32 with
 // f32-input MFMA (exact f32 products).
 #include "nd_common.hpp"
+#include "nd_b9.hpp"
 #include "../../include/nested_diffusion.h"
 #include <cstdlib>
 
@@ -261,7 +262,9 @@ extern "C" int nd_gemm_bias_act(const float* x, const void* w, const float* bias
 // ---------------------------------------------------------------------------------------------
 // LayerNorm over the last dim; one wave per row, two-pass (mean, then centred variance) in registers.
 // ---------------------------------------------------------------------------------------------
-template <int VPL>  // float4 per lane: dim <= 64*4*VPL
+// SPLIT: the result is written as a frag32b3 image (csrc/nd_b9.hpp) -- the input form of the Linear layer that follows every
+// LayerNorm of a ViT block -- instead of fp32 row-major: a lane's 4 consecutive columns are three 8-byte pieces.
+template <int VPL, bool SPLIT>  // float4 per lane: dim <= 64*4*VPL
 __global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ x, const float* __restrict__ gamma,
                                                    const float* __restrict__ beta, float* __restrict__ out, int rows, int dim,
                                                    float eps) {
@@ -302,25 +305,38 @@ __global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ x, 
             o.y = (v[i].y - mean) * rstd * g.y + b.y;
             o.z = (v[i].z - mean) * rstd * g.z + b.z;
             o.w = (v[i].w - mean) * rstd * g.w + b.w;
-            *reinterpret_cast<float4*>(out + (size_t)row * dim + c) = o;
+            if (SPLIT) nd_b9_store4(reinterpret_cast<bf16x8*>(out), dim >> 5, row, c, o.x, o.y, o.z, o.w);
+            else *reinterpret_cast<float4*>(out + (size_t)row * dim + c) = o;
         }
     }
 }
 
-extern "C" int nd_layernorm(const float* x, const float* gamma, const float* beta, float* out, int rows, int dim, float eps,
-                            void* stream) {
+template <bool SPLIT>
+static int launch_layernorm(const float* x, const float* gamma, const float* beta, float* out, int rows, int dim, float eps, void* stream) {
     if (!x || !gamma || !beta || !out) return nd_set_err(ND_ERR_ARG, "NULL tensor");
     if (rows < 1 || dim < 4 || (dim % 4) || dim > 64 * 4 * 8) return nd_set_err(ND_ERR_ARG, "dim must be a multiple of 4 in [4,2048]");
+    if (SPLIT && (dim % 32)) return nd_set_err(ND_ERR_ARG, "a split (frag32b3) output needs dim %% 32 == 0 (dim=%d)", dim);
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((rows + 3) / 4), block(256);
     const int vpl = (dim + 255) / 256;
-    if (vpl <= 1) hipLaunchKernelGGL((k_layernorm<1>), grid, block, 0, st, x, gamma, beta, out, rows, dim, eps);
-    else if (vpl <= 2) hipLaunchKernelGGL((k_layernorm<2>), grid, block, 0, st, x, gamma, beta, out, rows, dim, eps);
-    else if (vpl <= 3) hipLaunchKernelGGL((k_layernorm<3>), grid, block, 0, st, x, gamma, beta, out, rows, dim, eps);
-    else if (vpl <= 4) hipLaunchKernelGGL((k_layernorm<4>), grid, block, 0, st, x, gamma, beta, out, rows, dim, eps);
-    else hipLaunchKernelGGL((k_layernorm<8>), grid, block, 0, st, x, gamma, beta, out, rows, dim, eps);
+    if (vpl <= 1) hipLaunchKernelGGL((k_layernorm<1, SPLIT>), grid, block, 0, st, x, gamma, beta, out, rows, dim, eps);
+    else if (vpl <= 2) hipLaunchKernelGGL((k_layernorm<2, SPLIT>), grid, block, 0, st, x, gamma, beta, out, rows, dim, eps);
+    else if (vpl <= 3) hipLaunchKernelGGL((k_layernorm<3, SPLIT>), grid, block, 0, st, x, gamma, beta, out, rows, dim, eps);
+    else if (vpl <= 4) hipLaunchKernelGGL((k_layernorm<4, SPLIT>), grid, block, 0, st, x, gamma, beta, out, rows, dim, eps);
+    else hipLaunchKernelGGL((k_layernorm<8, SPLIT>), grid, block, 0, st, x, gamma, beta, out, rows, dim, eps);
     HIP_CHECK(hipGetLastError());
     return ND_OK;
+}
+
+extern "C" int nd_layernorm(const float* x, const float* gamma, const float* beta, float* out, int rows, int dim, float eps,
+                            void* stream) {
+    return launch_layernorm<false>(x, gamma, beta, out, rows, dim, eps, stream);
+}
+
+// the same LayerNorm with its result written as the frag32b3 image of [rows, dim] (dim % 32 == 0): the input of nd_gemm_split
+extern "C" int nd_layernorm_split(const float* x, const float* gamma, const float* beta, void* out_split, int rows, int dim, float eps,
+                                  void* stream) {
+    return launch_layernorm<true>(x, gamma, beta, (float*)out_split, rows, dim, eps, stream);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -333,7 +349,7 @@ extern "C" int nd_layernorm(const float* x, const float* gamma, const float* bet
 // ---------------------------------------------------------------------------------------------
 #define AT_MAXF 16  // up to 256 keys
 // RING form (the default fp32 kernel): nd_attention.hip, a translation unit of its own (accumulators kept in VGPRs).
-hipError_t nd_launch_attention_ring(const float* qkv, float* out, int B, int N, int heads, hipStream_t st);
+hipError_t nd_launch_attention_ring(const float* qkv, float* out, int B, int N, int heads, int split_out, hipStream_t st);
 
 // fp16-operand form (the fp16 mode; not a mode of the reference): q, k, v are rounded to fp16 as they are staged, both
 // contractions run on v_mfma_f32_16x16x32_f16 with fp32 accumulation, the softmax is fp32 and the normalised probabilities
@@ -467,7 +483,7 @@ static hipError_t launch_attention_h(const float* qkv, float* out, int B, int N,
     return hipGetLastError();
 }
 
-extern "C" int nd_attention(const float* qkv, float* out, int B, int N, int heads, int d, int dtype, void* stream) {
+static int attention_any(const float* qkv, float* out, int B, int N, int heads, int d, int dtype, int split_out, void* stream) {
     if (!qkv || !out) return nd_set_err(ND_ERR_ARG, "NULL tensor");
     if (d != 64) return nd_set_err(ND_ERR_ARG, "head dim must be 64 (got %d)", d);
     if (dtype != ND_DTYPE_F32 && dtype != ND_DTYPE_F16) return nd_set_err(ND_ERR_ARG, "unknown dtype %d", dtype);
@@ -475,7 +491,7 @@ extern "C" int nd_attention(const float* qkv, float* out, int B, int N, int head
     hipStream_t st = (hipStream_t)stream;
     const int nf = (N + 15) / 16;
 #define AT_CASE(NFV) case NFV: if (dtype == ND_DTYPE_F16) HIP_CHECK((launch_attention_h<NFV>(qkv, out, B, N, heads, st)));  \
-                               else HIP_CHECK(nd_launch_attention_ring(qkv, out, B, N, heads, st)); break;
+                               else HIP_CHECK(nd_launch_attention_ring(qkv, out, B, N, heads, split_out, st)); break;
     switch (nf) {
         AT_CASE(1) AT_CASE(2) AT_CASE(3) AT_CASE(4) AT_CASE(5) AT_CASE(6) AT_CASE(7) AT_CASE(8)
         AT_CASE(9) AT_CASE(10) AT_CASE(11) AT_CASE(12) AT_CASE(13) AT_CASE(14) AT_CASE(15) AT_CASE(16)
@@ -485,11 +501,20 @@ extern "C" int nd_attention(const float* qkv, float* out, int B, int N, int head
     return ND_OK;
 }
 
+extern "C" int nd_attention(const float* qkv, float* out, int B, int N, int heads, int d, int dtype, void* stream) {
+    return attention_any(qkv, out, B, N, heads, d, dtype, 0, stream);
+}
+
+// the fp32 attention with its result written as the frag32b3 image of [B*N, heads*64]: the input of the proj nd_gemm_split
+extern "C" int nd_attention_split(const float* qkv, void* out_split, int B, int N, int heads, int d, void* stream) {
+    return attention_any(qkv, (float*)out_split, B, N, heads, d, ND_DTYPE_F32, 1, stream);
+}
+
 // ---------------------------------------------------------------------------------------------
 // im2col for Conv2d(k = p, stride = p): cols[(b, py, px)][c*p*p + iy*p + ix] = img[b][c][py*p+iy][px*p+ix]
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_patchify(const float* __restrict__ img, float* __restrict__ cols, int B, int Cin,
-                                                  int Himg, int Wimg, int p) {
+                                                  int Himg, int Wimg, int p, int split_out) {
     const int gw = Wimg / p, gh = Himg / p;
     const size_t rowlen = (size_t)Cin * p * p;
     const size_t total4 = (size_t)B * gh * gw * rowlen / 4;
@@ -500,17 +525,28 @@ __global__ __launch_bounds__(256) void k_patchify(const float* __restrict__ img,
         const int c = col / (p * p), iy = (col / p) % p, ix = col % p;
         const int b = (int)(tok / (gh * gw)), py = (int)(tok % (gh * gw)) / gw, px = (int)(tok % gw);
         const float4 v = *reinterpret_cast<const float4*>(img + (((size_t)b * Cin + c) * Himg + (py * p + iy)) * Wimg + px * p + ix);
-        *reinterpret_cast<float4*>(cols + e) = v;
+        if (split_out) nd_b9_store4(reinterpret_cast<bf16x8*>(cols), (int)(rowlen >> 5), (int)tok, col, v.x, v.y, v.z, v.w);
+        else *reinterpret_cast<float4*>(cols + e) = v;
     }
 }
 
-extern "C" int nd_patchify(const float* img, float* cols, int B, int Cin, int Himg, int Wimg, int p, void* stream) {
+static int patchify_any(const float* img, float* cols, int B, int Cin, int Himg, int Wimg, int p, int split_out, void* stream) {
     if (!img || !cols) return nd_set_err(ND_ERR_ARG, "NULL tensor");
     if (B < 1 || Cin < 1 || p < 4 || (p % 4) || Himg % p || Wimg % p || (Wimg % 4))
         return nd_set_err(ND_ERR_ARG, "patch size must be a multiple of 4 dividing the image");
+    if (split_out && ((Cin * p * p) % 32)) return nd_set_err(ND_ERR_ARG, "a split (frag32b3) output needs Cin*p*p %% 32 == 0");
     const size_t total4 = (size_t)B * Cin * Himg * Wimg / 4;
     const unsigned blocks = (unsigned)((total4 + 255) / 256 > 4096 ? 4096 : (total4 + 255) / 256);
-    hipLaunchKernelGGL(k_patchify, dim3(blocks), dim3(256), 0, (hipStream_t)stream, img, cols, B, Cin, Himg, Wimg, p);
+    hipLaunchKernelGGL(k_patchify, dim3(blocks), dim3(256), 0, (hipStream_t)stream, img, cols, B, Cin, Himg, Wimg, p, split_out);
     HIP_CHECK(hipGetLastError());
     return ND_OK;
+}
+
+extern "C" int nd_patchify(const float* img, float* cols, int B, int Cin, int Himg, int Wimg, int p, void* stream) {
+    return patchify_any(img, cols, B, Cin, Himg, Wimg, p, 0, stream);
+}
+
+// the same im2col written as the frag32b3 image of [B*(Himg/p)*(Wimg/p), Cin*p*p]: the input of the patch-embedding nd_gemm_split
+extern "C" int nd_patchify_split(const float* img, void* cols_split, int B, int Cin, int Himg, int Wimg, int p, void* stream) {
+    return patchify_any(img, (float*)cols_split, B, Cin, Himg, Wimg, p, 1, stream);
 }

@@ -72,11 +72,21 @@ class VisionTransformer:
         w = self.p["patch_embed.proj.weight"]
         self.embed_dim, self.in_chans, self.patch = w.shape[0], w.shape[1], w.shape[-1]
         self.pe_w = w.reshape(self.embed_dim, -1).contiguous()
+        gemm_keys = [k for k in self.p if k.startswith("blocks.") and
+                     k.endswith(("attn.qkv.weight", "attn.proj.weight", "mlp.fc1.weight", "mlp.fc2.weight"))]
+        # fp32 mode: the Linear layers run on the bf16 matrix pipe with exact fp32 products (nd_gemm_split) wherever the shapes allow
+        # it (every GEMM depth a multiple of 32: 768 / 3072 / 3*16*16 for ViT-B/16); the weights are then held as frag32b3 images
+        # ONLY.  ND_GEMM_F32=mfma_f32 keeps the f32-input-MFMA kernels (and row-major fp32 weights).
+        self.split = (self.dtype == "f32" and os.environ.get("ND_GEMM_F32", "b9") != "mfma_f32" and self.pe_w.shape[1] % 32 == 0
+                      and all(self.p[k].shape[1] % 32 == 0 for k in gemm_keys))
+        if self.split:
+            self.pe_w = ops.split_rows(self.pe_w)
+            for k in gemm_keys:
+                self.p[k] = ops.split_rows(self.p[k])
         if self.dtype == "f16":
             self.pe_w = self.pe_w.half()
-            for k in list(self.p):
-                if k.startswith("blocks.") and k.endswith(("attn.qkv.weight", "attn.proj.weight", "mlp.fc1.weight", "mlp.fc2.weight")):
-                    self.p[k] = self.p[k].half()
+            for k in gemm_keys:
+                self.p[k] = self.p[k].half()
         self.num_heads = num_heads
         self.depth = 1 + max(int(k.split(".")[1]) for k in self.p if k.startswith("blocks."))
         if self.embed_dim // num_heads != 64:
@@ -162,18 +172,22 @@ class GuidingConditioner:
         cfg.mlp_hidden = vit.p["blocks.0.mlp.fc1.weight"].shape[0]
         cfg.n_blocks, cfg.n_mlps = vit.depth, len(self.mlps)
         cfg.mlp_widths[0], cfg.mlp_widths[1], cfg.mlp_widths[2] = widths
-        cfg.num_classes, cfg.max_batch, cfg.max_tokens, cfg.operand_dtype, cfg.ln_eps = n_cls, max(B, 1), n_tok + 1, dt, LN_EPS
+        cfg.num_classes, cfg.max_batch, cfg.max_tokens, cfg.ln_eps = n_cls, max(B, 1), n_tok + 1, LN_EPS
+        cfg.operand_dtype = _lib.ND_DTYPE_F32_SPLIT if vit.split else dt
+
+        def dptr(v):
+            return v.data.data_ptr() if isinstance(v, ops.SplitMatrix) else v.data_ptr()
         h = C.c_void_p()
         check(lib.nd_cond_create(C.byref(cfg), C.byref(h)), "nd_cond_create")
         nbytes = lib.nd_cond_workspace_bytes(C.byref(cfg))
         ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=vit.device)
         check(lib.nd_cond_bind_workspace(h, (ws.data_ptr() + 255) & ~255, nbytes), "nd_cond_bind_workspace")
-        pe = _lib.NdPatchEmbedWeights(vit.pe_w.data_ptr(), vit.p["patch_embed.proj.bias"].data_ptr())
+        pe = _lib.NdPatchEmbedWeights(dptr(vit.pe_w), vit.p["patch_embed.proj.bias"].data_ptr())
         check(lib.nd_cond_set_patch_embed(h, C.byref(pe)), "nd_cond_set_patch_embed")
         for i in range(vit.depth):
             w = _lib.NdVitBlockWeights()
             for field, key in _lib.VIT_BLOCK_FIELDS:
-                setattr(w, field, vit.p[f"blocks.{i}.{key}"].data_ptr())
+                setattr(w, field, dptr(vit.p[f"blocks.{i}.{key}"]))
             check(lib.nd_cond_set_block(h, i, C.byref(w)), "nd_cond_set_block")
         for i, m in enumerate(self.mlps):
             w = _lib.NdMlpWeights()

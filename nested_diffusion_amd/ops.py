@@ -2,6 +2,7 @@
 Every function launches HIP kernels on torch's current stream; inputs must live on the GPU."""
 from __future__ import annotations
 
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -79,12 +80,84 @@ def linear(x: torch.Tensor, weight, bias: Optional[torch.Tensor] = None, act=Non
     return out
 
 
-def gemm_bias_act(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, act=None,
+class SplitMatrix:
+    """frag32b3 image of an fp32 [rows, K] matrix (csrc/nd_b9.hpp): every value as its three exact bf16 pieces, in the lane order of
+    v_mfma_f32_16x16x32_bf16 -- the operand form of nd_gemm_split.  Weights are converted once (at load); activations are written in
+    this form by the operator that produces them."""
+
+    def __init__(self, rows: int, K: int, device, data: Optional[torch.Tensor] = None):
+        nbytes = _lib.load().nd_split_bytes(int(rows), int(K))
+        if nbytes == 0:
+            raise ValueError(f"no frag32b3 image for a [{rows}, {K}] matrix (K must be a positive multiple of 32)")
+        self.rows, self.K = int(rows), int(K)
+        self.data = data if data is not None else torch.empty(nbytes, dtype=torch.uint8, device=device)
+        if self.data.numel() < nbytes or not self.data.is_cuda:
+            raise ValueError("image buffer too small or not on the GPU")
+
+    @property
+    def shape(self):
+        return (self.rows, self.K)
+
+    @property
+    def device(self):
+        return self.data.device
+
+
+def split_rows(x: torch.Tensor, out: Optional[SplitMatrix] = None) -> SplitMatrix:
+    """fp32 [rows, K] -> its frag32b3 image (exact)."""
+    x = _f32(x, "x")
+    rows, K = x.shape
+    out = out if out is not None else SplitMatrix(rows, K, x.device)
+    check(_lib.load().nd_split_rows(ptr(x), ptr(out.data), rows, K, _stream(x)), "nd_split_rows")
+    return out
+
+
+def join_rows(s: SplitMatrix) -> torch.Tensor:
+    """frag32b3 image -> fp32 [rows, K] (the three pieces summed: exact)."""
+    out = torch.empty(s.rows, s.K, dtype=torch.float32, device=s.device)
+    check(_lib.load().nd_join_rows(ptr(s.data), ptr(out), s.rows, s.K, _stream(out)), "nd_join_rows")
+    return out
+
+
+def gemm_split(x, weight: SplitMatrix, bias: Optional[torch.Tensor] = None, act=None, residual: Optional[torch.Tensor] = None,
+               want_out: bool = True, want_split: bool = False, use_workspace: bool = True):
+    """act(x @ weight.T + bias) + residual with exact fp32 products on the bf16 matrix pipe (nd_gemm_split).  x: fp32 [M, K] (split
+    here) or a SplitMatrix.  Returns the fp32 result, its frag32b3 image (want_split; N % 32 == 0), or both as a tuple."""
+    lib = _lib.load()
+    xs = x if isinstance(x, SplitMatrix) else split_rows(x)
+    M, K = xs.shape
+    N = weight.rows
+    if weight.K != K:
+        raise ValueError(f"weight is {weight.shape}, x is {xs.shape}")
+    dev = xs.device
+    bias = _f32(bias, "bias") if bias is not None else None
+    residual = _f32(residual, "residual") if residual is not None else None
+    if residual is not None and tuple(residual.shape) != (M, N):
+        raise ValueError("residual must be [M, N]")
+    out = torch.empty(M, N, dtype=torch.float32, device=dev) if want_out else None
+    osp = SplitMatrix(M, N, dev) if want_split else None
+    nbytes = lib.nd_gemm_split_workspace_bytes(M, K, N) if use_workspace else 0
+    ws = _workspace(nbytes, dev) if nbytes else None
+    check(lib.nd_gemm_split(ptr(xs.data), ptr(weight.data), ptr(bias), ptr(residual), ptr(out), ptr(osp.data) if osp else None, M, K, N,
+                            ACT[act], ptr(ws), ws.numel() if ws is not None else 0, _stream(xs.data)), "nd_gemm_split")
+    if want_out and want_split:
+        return out, osp
+    return osp if want_split else out
+
+
+def gemm_bias_act(x: torch.Tensor, weight, bias: Optional[torch.Tensor] = None, act=None,
                   residual: Optional[torch.Tensor] = None) -> torch.Tensor:
     """act(x @ weight.T + bias) + residual for large row counts (ViT token matrices).
+    fp32 `weight` (or a SplitMatrix made from one) with K % 32 == 0: exact fp32 products on the bf16 matrix pipe (gemm_split; set
+    ND_GEMM_F32=mfma_f32 for the f32-input-MFMA kernel, which also takes every K % 16 == 0).
     A float16 `weight` selects the fp16-operand kernel (x rounded to fp16 on the fly, fp32 accumulate / out; K % 32 == 0)."""
     lib = _lib.load()
+    if isinstance(weight, SplitMatrix):
+        return gemm_split(x, weight, bias, act, residual)
     x = _f32(x, "x")
+    if (weight.is_cuda and weight.dtype == torch.float32 and x.shape[1] % 32 == 0 and weight.dim() == 2
+            and os.environ.get("ND_GEMM_F32", "b9") != "mfma_f32"):
+        return gemm_split(x, split_rows(weight), bias, act, residual)
     if not weight.is_cuda:
         raise _lib.NdError("weight must be a GPU tensor (no CPU fallback)")
     if weight.dtype == torch.float16:

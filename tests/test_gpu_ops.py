@@ -85,6 +85,66 @@ def test_gemm_bias_act(M, K, N, act, res):
     _close(out, ref, 2e-5)
 
 
+@pytest.mark.parametrize("rows,K", [(6272, 768), (130, 64), (1, 32), (17, 3072)])
+def test_split_rows_is_exact(rows, K):
+    """frag32b3 (csrc/nd_b9.hpp): an fp32 value IS the sum of its three bf16 pieces -- bit for bit, including values whose low
+    pieces vanish, negative zero aside -- so nothing is rounded on the way onto the bf16 matrix pipe."""
+    from nested_diffusion_amd import ops
+    g = torch.Generator().manual_seed(rows)
+    x = torch.randn(rows, K, generator=g) * torch.exp(4 * torch.randn(rows, 1, generator=g))
+    x[0, :8] = torch.tensor([0.0, 1.0, -1.0, 2.0 ** -100, 1.0 + 2.0 ** -23, 3.0e38, -7.5e-30, 1.0 / 3.0])
+    s = ops.split_rows(x.cuda())
+    assert s.data.numel() == ((rows + 15) // 16) * (K // 32) * 3072
+    assert torch.equal(ops.join_rows(s).cpu(), x)
+
+
+@pytest.mark.parametrize("M,K,N,act,res", [(6272, 768, 2304, None, False), (6272, 768, 768, None, True), (6272, 768, 3072, "gelu", False),
+                                           (6272, 3072, 768, None, True),                      # 8-wave shape, k-split tail + fixup
+                                           (392, 768, 2304, None, False), (6250, 768, 3040, "gelu", True),   # ragged M and N edges
+                                           (130, 64, 70, None, True), (1, 32, 1, "relu", False), (200, 2048, 96, "gelu", True)])
+def test_gemm_split_exact_products_on_the_bf16_pipe(M, K, N, act, res):
+    """nd_gemm_split against an fp64 product of the same fp32 inputs at the tolerance of the f32-MFMA kernel's test (2e-5), with
+    and without the k-split workspace, reproducible run to run; its frag32b3 output is exactly the fp32 output."""
+    from nested_diffusion_amd import ops
+    g = torch.Generator().manual_seed(M + N)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    r = torch.randn(M, N, generator=g) if res else None
+    ws, xs = ops.split_rows(w.cuda()), ops.split_rows(x.cuda())
+    rc = r.cuda() if res else None
+    out = ops.gemm_split(xs, ws, b.cuda(), act=act, residual=rc)
+    ref = (x.double() @ w.double().T).float() + b
+    ref = {None: lambda v: v, "relu": F.relu, "gelu": F.gelu}[act](ref)
+    if res:
+        ref = ref + r
+    _close(out, ref, 2e-5)
+    assert torch.equal(out, ops.gemm_split(xs, ws, b.cuda(), act=act, residual=rc))
+    whole = ops.gemm_split(xs, ws, b.cuda(), act=act, residual=rc, use_workspace=False)
+    _close(whole, ref, 2e-5)
+    if N % 32 == 0:
+        o2, osp = ops.gemm_split(xs, ws, b.cuda(), act=act, residual=rc, want_out=True, want_split=True)
+        assert torch.equal(o2, out) and torch.equal(ops.join_rows(osp), out)
+        only = ops.gemm_split(xs, ws, b.cuda(), act=act, residual=rc, want_out=False, want_split=True)
+        assert torch.equal(ops.join_rows(only), out)
+
+
+def test_gemm_split_argument_checks():
+    from nested_diffusion_amd import _lib, ops
+    lib = _lib.load()
+    assert lib.nd_split_bytes(16, 48) == 0 and lib.nd_split_bytes(0, 32) == 0 and lib.nd_split_bytes(17, 64) == 2 * 2 * 3072
+    x = ops.split_rows(torch.randn(32, 64).cuda())
+    w = ops.split_rows(torch.randn(48, 64).cuda())
+    st = torch.cuda.current_stream().cuda_stream
+    out = torch.empty(32, 48, device="cuda")
+    assert lib.nd_gemm_split(_lib.ptr(x.data), _lib.ptr(w.data), None, None, None, None, 32, 64, 48, 0, None, 0, st) != 0      # no output at all
+    assert lib.nd_gemm_split(_lib.ptr(x.data), _lib.ptr(w.data), None, None, _lib.ptr(out), _lib.ptr(out), 32, 64, 48, 0, None, 0, st) != 0
+    assert b"N % 32" in lib.nd_last_error()                                                                              # split output needs N % 32 == 0
+    assert lib.nd_gemm_split(_lib.ptr(x.data), _lib.ptr(w.data), None, None, _lib.ptr(out), None, 32, 48, 48, 0, None, 0, st) != 0   # K % 32
+    with pytest.raises(ValueError):
+        ops.SplitMatrix(4, 40, "cuda")
+
+
 def test_gemm_without_workspace_matches_split_path():
     """nd_gemm_bias_act with a NULL workspace computes every tile whole: same values up to summation order."""
     from nested_diffusion_amd import _lib, ops

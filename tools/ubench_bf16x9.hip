@@ -123,7 +123,8 @@ __global__ __launch_bounds__(256) void k_split3(const float* __restrict__ x, bf1
 // NT = 9: all piece products; NT = 6: without a2 b3, a3 b2, a3 b3 (<= 2^-24 of the product each) -- labelled, not the "exact" form.
 template <int FA, int FB, int NS, int NT>
 __global__ __launch_bounds__(256) void k_gemm_b9(const bf16x8* __restrict__ wP, const bf16x8* __restrict__ xP, float* __restrict__ out,
-                                                 int M, int N, int K, long wStride, long xStride, int TM, int TN, int nwg) {
+                                                 int M, int N, int K, long wStride, long xStride, int TM, int TN, int nwg,
+                                                 unsigned long long* __restrict__ clk) {
     constexpr int NFRAG = 2 * FA + 2 * FB;          // fragments per slot
     constexpr int NP = NFRAG * 3 / 4;               // LDS-DMA pieces per wave per step
     static_assert((NFRAG * 3) % 4 == 0, "pieces must deal evenly to 4 waves");
@@ -185,6 +186,7 @@ __global__ __launch_bounds__(256) void k_gemm_b9(const bf16x8* __restrict__ wP, 
     __builtin_amdgcn_s_barrier();
     B9_READ(0, 0)
     __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long tc0 = __builtin_amdgcn_s_memtime(), tr0 = __builtin_amdgcn_s_memrealtime();
     constexpr int U = (NS % 2 == 0) ? NS : 2 * NS;
     constexpr int NM = NT * FA * FB, NMEM = NP + 3 * (FA + FB), RATIO = NM / NMEM > 0 ? NM / NMEM : 1;
     for (int s = 0; s < nk; s += U) {
@@ -212,6 +214,7 @@ __global__ __launch_bounds__(256) void k_gemm_b9(const bf16x8* __restrict__ wP, 
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (clk && tid == 0) { clk[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - tc0; clk[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - tr0; }
 #undef B9_STAGE
 #undef B9_READ
 #undef B9_TERM
@@ -223,6 +226,174 @@ __global__ __launch_bounds__(256) void k_gemm_b9(const bf16x8* __restrict__ wP, 
         for (int j = 0; j < FB; ++j) {
             const int n = (tn * 2 * FA + wn * FA + i) * 16 + 4 * (lane >> 4), m = (tm * 2 * FB + wm * FB + j) * 16 + (lane & 15);
             if (m < M && n + 3 < N) *reinterpret_cast<f32x4*>(o + (size_t)m * N + n) = acc[i][j];
+        }
+}
+
+
+// HBM streaming filler for the "mixed load" measurement: what the chip clocks a GEMM at when it runs between memory-bound kernels
+__global__ __launch_bounds__(256) void k_stream(const f32x4* __restrict__ p, float* __restrict__ out, size_t n) {
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) a += __builtin_nontemporal_load(p + i);
+    if (a[0] + a[1] + a[2] + a[3] == 12345.678f) out[threadIdx.x] = a[0];
+}
+
+// ---- second form: any wave grid (WN x WM waves of FA x FB fragments), k-split tail, two issue schedules -------------------------
+// SCHED 0: memory instructions dealt evenly between the MFMAs of a step.  SCHED 1: the fragment reads of step j+1 first (one per 2
+// MFMAs), then the LDS-DMA pieces of step j+NS (one per 4), and the last MFMAs of the step with nothing between them, so that the
+// counted wait + barrier at the top of the next step find every read retired.
+template <int FA, int FB, int WN, int WM, int NS, int SCHED>
+__global__ __launch_bounds__(64 * WN * WM) void k_gemm_b9v2(const bf16x8* __restrict__ wP, const bf16x8* __restrict__ xP, float* __restrict__ out,
+                                                            int M, int N, int K, long wStride, long xStride, int TM, int TN, int n_full, int split,
+                                                            f32x4* __restrict__ part, unsigned long long* __restrict__ clk) {
+    constexpr int NW = WN * WM, NFRAG = WN * FA + WM * FB, NPC = NFRAG * 3;
+    constexpr int NP = (NPC + NW - 1) / NW;                       // LDS-DMA pieces per wave per step (the last wave may have fewer)
+    // (where NPC % NW != 0 the last waves re-issue the last piece: same bytes to the same place, every wave counts NP per step)
+    extern __shared__ __attribute__((aligned(16))) bf16x8 lds[];   // [NS][NFRAG][3][64]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave / WM, wm = wave % WM;
+    int bid = blockIdx.x, slab = -1, rem_index = 0;
+    if (bid < n_full) {
+        const int q = n_full / 8, r = n_full % 8, xcd = bid % 8, loc = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    } else {
+        const int j = bid - n_full;
+        rem_index = j / split; slab = j % split; bid = n_full + rem_index;
+    }
+    const int per = TM * TN, member = bid / per, r2 = bid - member * per, tn = r2 / TM, tm = r2 - tn * TM;
+    const int nkb = K / 32, nfr = (N + 15) >> 4, mfr = (M + 15) >> 4;
+    const int c0 = slab < 0 ? 0 : (int)((long)slab * nkb / split), c1 = slab < 0 ? nkb : (int)((long)(slab + 1) * nkb / split);
+    const int nk = c1 - c0;
+    const bf16x8* wb = wP + (size_t)member * wStride;
+    const bf16x8* xb = xP + (size_t)member * xStride;
+    const bf16x8* src[NP];
+#pragma unroll
+    for (int u = 0; u < NP; ++u) {
+        const int e = min(wave * NP + u, NPC - 1), f = e / 3, pl = e % 3;
+        const bf16x8* base = f < WN * FA ? wb + ((size_t)min(tn * WN * FA + f, nfr - 1) * nkb + c0) * 192
+                                         : xb + ((size_t)min(tm * WM * FB + f - WN * FA, mfr - 1) * nkb + c0) * 192;
+        src[u] = base + pl * 64 + lane;
+    }
+#define V2_STAGE(slot, step)                                                                                                        \
+    {                                                                                                                               \
+        _Pragma("unroll") for (int pc_ = 0; pc_ < NP; ++pc_)                                                                        \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[pc_] + (size_t)(step) * 192),      \
+                                             (__attribute__((address_space(3))) void*)&lds[((slot) * NPC + min(wave * NP + pc_, NPC - 1)) * 64], 16, 0, 0); \
+    }
+#define V2_READ(set, slot)                                                                                                          \
+    {                                                                                                                               \
+        _Pragma("unroll") for (int p = 0; p < 3; ++p) {                                                                             \
+            _Pragma("unroll") for (int i = 0; i < FA; ++i) fw[set][p][i] = lds[(((slot) * NFRAG + wn * FA + i) * 3 + p) * 64 + lane]; \
+            _Pragma("unroll") for (int j = 0; j < FB; ++j) fx[set][p][j] = lds[(((slot) * NFRAG + WN * FA + wm * FB + j) * 3 + p) * 64 + lane]; \
+        }                                                                                                                           \
+    }
+#define V2_TERM(set, p, q)                                                                                                          \
+    {                                                                                                                               \
+        _Pragma("unroll") for (int i = 0; i < FA; ++i)                                                                              \
+            _Pragma("unroll") for (int j = 0; j < FB; ++j)                                                                          \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[set][p][i], fx[set][q][j], acc[i][j], 0, 0, 0);              \
+    }
+#define V2_SYNC()                                                                                                                   \
+    {                                                                                                                               \
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NP * (NS - 2)) : "memory");                                             \
+        __builtin_amdgcn_s_barrier();                                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                                                          \
+    }
+    f32x4 acc[FA][FB];
+#pragma unroll
+    for (int i = 0; i < FA; ++i)
+#pragma unroll
+        for (int j = 0; j < FB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 fw[2][3][FA], fx[2][3][FB];
+#pragma unroll
+    for (int u = 0; u < NS; ++u) V2_STAGE(u, min(u, nk - 1))
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP * (NS - 1)) : "memory");
+    __builtin_amdgcn_s_barrier();
+    V2_READ(0, 0)
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long tc0 = __builtin_amdgcn_s_memtime(), tr0 = __builtin_amdgcn_s_memrealtime();
+    constexpr int U = (NS % 2 == 0) ? NS : 2 * NS;
+    constexpr int NM = 9 * FA * FB, NRD = 3 * (FA + FB), NMEM = NP + NRD, RATIO = NM / NMEM > 0 ? NM / NMEM : 1;
+    for (int s = 0; s < nk; s += U) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (s + u < nk) {
+                V2_SYNC()
+                if (SCHED == 0) { V2_STAGE(u % NS, min(s + u + NS, nk - 1)) V2_READ((u + 1) & 1, (u + 1) % NS) }
+                else { V2_READ((u + 1) & 1, (u + 1) % NS) V2_STAGE(u % NS, min(s + u + NS, nk - 1)) }
+                V2_TERM(u & 1, 2, 2) V2_TERM(u & 1, 2, 1) V2_TERM(u & 1, 1, 2)
+                V2_TERM(u & 1, 2, 0) V2_TERM(u & 1, 0, 2) V2_TERM(u & 1, 1, 1) V2_TERM(u & 1, 1, 0) V2_TERM(u & 1, 0, 1) V2_TERM(u & 1, 0, 0)
+                if (SCHED == 0) {
+#pragma unroll
+                    for (int k = 0; k < NP; ++k) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, RATIO, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    }
+#pragma unroll
+                    for (int k = 0; k < NRD; ++k) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, RATIO, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, NM - RATIO * NMEM, 0);
+                } else {
+                    constexpr int R1 = (2 * NRD + 3 * NP <= NM - 8) ? 2 : 1, R2 = (R1 * NRD + 3 * NP <= NM - 8) ? 3 : ((R1 * NRD + 2 * NP <= NM - 4) ? 2 : 1);
+#pragma unroll
+                    for (int k = 0; k < NRD; ++k) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, R1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+#pragma unroll
+                    for (int k = 0; k < NP; ++k) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, R2, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, NM - R1 * NRD - R2 * NP, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (clk && tid == 0) { clk[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - tc0; clk[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - tr0; }
+#undef V2_STAGE
+#undef V2_READ
+#undef V2_TERM
+#undef V2_SYNC
+    if (slab >= 0) {     // raw accumulators of a k-slab: [remainder tile][slab][wave][fragment][lane], 1 KiB per fragment
+        f32x4* pt = part + (((size_t)rem_index * split + slab) * NW + wave) * (FA * FB) * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < FA; ++i)
+#pragma unroll
+            for (int j = 0; j < FB; ++j) pt[(i * FB + j) * 64] = acc[i][j];
+        return;
+    }
+    float* o = out + (size_t)member * M * N;
+#pragma unroll
+    for (int i = 0; i < FA; ++i)
+#pragma unroll
+        for (int j = 0; j < FB; ++j) {
+            const int n = ((tn * WN + wn) * FA + i) * 16 + 4 * (lane >> 4), m = ((tm * WM + wm) * FB + j) * 16 + (lane & 15);
+            if (m < M && n + 3 < N) *reinterpret_cast<f32x4*>(o + (size_t)m * N + n) = acc[i][j];
+        }
+}
+
+// sums the k-slabs of the remainder tiles in slab order and stores them: one wave per (remainder tile, wave sub-tile)
+template <int FA, int FB, int WN, int WM>
+__global__ __launch_bounds__(64) void k_b9_fixup(const f32x4* __restrict__ part, float* __restrict__ out, int M, int N, int TM, int TN, int n_full,
+                                                 int split) {
+    constexpr int NW = WN * WM;
+    const int lane = threadIdx.x, wave = blockIdx.x % NW, ri = blockIdx.x / NW;
+    const int wn = wave / WM, wm = wave % WM;
+    const int bid = n_full + ri, per = TM * TN, member = bid / per, r2 = bid - member * per, tn = r2 / TM, tm = r2 - tn * TM;
+    float* o = out + (size_t)member * M * N;
+#pragma unroll
+    for (int i = 0; i < FA; ++i)
+#pragma unroll
+        for (int j = 0; j < FB; ++j) {
+            f32x4 a = part[(((size_t)ri * split + 0) * NW + wave) * (FA * FB) * 64 + (i * FB + j) * 64 + lane];
+            for (int k = 1; k < split; ++k) a += part[(((size_t)ri * split + k) * NW + wave) * (FA * FB) * 64 + (i * FB + j) * 64 + lane];
+            const int n = ((tn * WN + wn) * FA + i) * 16 + 4 * (lane >> 4), m = ((tm * WM + wm) * FB + j) * 16 + (lane & 15);
+            if (m < M && n + 3 < N) *reinterpret_cast<f32x4*>(o + (size_t)m * N + n) = a;
         }
 }
 
@@ -256,10 +427,22 @@ static void run_gemm(const Shape& sh, const float* dW, const float* dX, bf16x8* 
             hipLaunchKernelGGL(k_split3, dim3((unsigned)((nb * 64 + 255) / 256)), dim3(256), 0, 0, dX + (size_t)b * sh.M * sh.K, xP + b * xStride, sh.M, sh.K, Mpad);
         }
     };
-    auto gemm = [&]() { hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), lds_bytes, 0, wP, xP, dOut, sh.M, sh.N, sh.K, wStride, xStride, TM, TN, nwg); };
+    static unsigned long long* dclk = nullptr;
+    if (!dclk) CK(hipMalloc(&dclk, 16 * 16384));
+    auto gemm = [&]() { hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), lds_bytes, 0, wP, xP, dOut, sh.M, sh.N, sh.K, wStride, xStride, TM, TN, nwg, dclk); };
     split_x(); gemm(); gemm();
     CK(hipDeviceSynchronize());
-    const int reps = 20;
+    // the chip's clock under load settles over hundreds of milliseconds: keep the kernel running for ~0.6 s before timing it
+    {
+        hipEvent_t w0, w1;
+        CK(hipEventCreate(&w0)); CK(hipEventCreate(&w1));
+        CK(hipEventRecord(w0)); gemm(); CK(hipEventRecord(w1)); CK(hipEventSynchronize(w1));
+        float one = 0; CK(hipEventElapsedTime(&one, w0, w1));
+        const int nwarm = (int)(600.0f / (one > 0.01f ? one : 0.01f));
+        for (int r = 0; r < nwarm; ++r) gemm();
+        CK(hipDeviceSynchronize());
+    }
+    const int reps = 200;
     CK(hipEventRecord(e0));
     for (int r = 0; r < reps; ++r) gemm();
     CK(hipEventRecord(e1));
@@ -306,11 +489,127 @@ static void run_gemm(const Shape& sh, const float* dW, const float* dX, bf16x8* 
         printf("    [debug] split planes that do not sum back exactly: %ld of %ld; non-finite outputs %ld of %zu; out[0..3] = %g %g %g %g\n", bad,
                (long)sh.M * sh.K, nonfinite, hOut.size(), hOut[0], hOut[1], hOut[2], hOut[3]);
     }
+    std::vector<unsigned long long> hc(2 * (size_t)nwg);
+    CK(hipMemcpy(hc.data(), dclk, 16 * (size_t)nwg, hipMemcpyDeviceToHost));
+    double cyc = 0, ghz = 0;
+    for (int b = 0; b < nwg; ++b) { cyc += (double)hc[2 * b]; ghz += (double)hc[2 * b] / (double)hc[2 * b + 1] * 0.1; }
+    cyc /= nwg; ghz /= nwg;
+    const double ideal = (double)NT * FA * FB * 16.0;
+    printf("    main loop: %.0f cycles per K-step per workgroup (MFMA-only %.0f x %d resident = %.0f; ratio %.2f), in-kernel clock %.2f GHz\n",
+           cyc / (sh.K / 32), ideal, occ, ideal * occ, cyc / (sh.K / 32) / (ideal * occ), ghz);
     const double rounds = (double)nwg / (ncu * (occ > 0 ? occ : 1));
     printf("  tile %3dx%-3d NS=%d terms=%d  %d wg/CU  %5d wgs (%.2f rounds)  gemm %7.1f us = %6.1f TF-eq | + x split %5.1f us -> %6.1f TF-eq"
            " | vs library %.0f us: %.2fx (%.2fx incl. split) | err max/maxref %.2e rms %.2e\n",
            BN, BM, NS, NT, occ, nwg, rounds, us_g, flop / us_g * 1e-6, us_s, flop / (us_g + us_s) * 1e-6, sh.yard_us, sh.yard_us / us_g,
            sh.yard_us / (us_g + us_s), maxerr / maxref, sqrt(se / sr));
+    fflush(stdout);
+}
+
+
+template <int FA, int FB, int WN, int WM, int NS, int SCHED>
+static void run_gemm2(const Shape& sh, const float* dW, const float* dX, bf16x8* wP, bf16x8* xP, float* dOut, const std::vector<float>& hW,
+                      const std::vector<float>& hX, int ncu, bool tail_split) {
+    const int BM = WM * FB * 16, BN = WN * FA * 16, NW = WN * WM;
+    const int TM = (sh.M + BM - 1) / BM, TN = (sh.N + BN - 1) / BN, tiles = sh.batch * TM * TN;
+    const int Mpad = TM * BM, Npad = TN * BN;
+    const size_t lds_bytes = (size_t)NS * (WN * FA + WM * FB) * 3 * 1024;
+    auto kern = k_gemm_b9v2<FA, FB, WN, WM, NS, SCHED>;
+    CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    int occ = 0;
+    CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 64 * NW, lds_bytes));
+    const int slots = ncu * (occ > 0 ? occ : 1), nkb = sh.K / 32;
+    int n_full = tiles, rem = 0, split = 1;
+    if (tail_split && tiles % slots) {
+        n_full = (tiles / slots) * slots; rem = tiles - n_full;
+        double best = 1e9;
+        const int cand[] = {1, 2, 3, 4, 6, 8, 12};
+        for (int c : cand) if (nkb / c >= 4) { const double t = (double)((rem * c + slots - 1) / slots) / c; if (t < best - 1e-9) { best = t; split = c; } }
+        if (split == 1) { n_full = tiles; rem = 0; }
+    }
+    const long wStride = (long)(Npad / 16) * nkb * 192, xStride = (long)(Mpad / 16) * nkb * 192;
+    static unsigned long long* dclk = nullptr;
+    static f32x4* part = nullptr;
+    if (!dclk) { CK(hipMalloc(&dclk, 16 * 65536)); CK(hipMalloc(&part, (size_t)256 << 20)); }
+    for (int b = 0; b < sh.batch; ++b) {
+        const long nb = (long)(Npad / 16) * nkb, mb = (long)(Mpad / 16) * nkb;
+        hipLaunchKernelGGL(k_split3, dim3((unsigned)((nb * 64 + 255) / 256)), dim3(256), 0, 0, dW + (size_t)b * sh.N * sh.K, wP + b * wStride, sh.N, sh.K, Npad);
+        hipLaunchKernelGGL(k_split3, dim3((unsigned)((mb * 64 + 255) / 256)), dim3(256), 0, 0, dX + (size_t)b * sh.M * sh.K, xP + b * xStride, sh.M, sh.K, Mpad);
+    }
+    const int nwg = n_full + rem * split;
+    auto gemm = [&]() {
+        hipLaunchKernelGGL(kern, dim3(nwg), dim3(64 * NW), lds_bytes, 0, wP, xP, dOut, sh.M, sh.N, sh.K, wStride, xStride, TM, TN, n_full, split, part, dclk);
+        if (rem) hipLaunchKernelGGL((k_b9_fixup<FA, FB, WN, WM>), dim3(rem * NW), dim3(64), 0, 0, part, dOut, sh.M, sh.N, TM, TN, n_full, split);
+    };
+    CK(hipMemset(dOut, 0, (size_t)sh.batch * sh.M * sh.N * 4));
+    gemm(); gemm();
+    CK(hipDeviceSynchronize());
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    {
+        CK(hipEventRecord(e0)); gemm(); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float one = 0; CK(hipEventElapsedTime(&one, e0, e1));
+        const int nwarm = (int)(600.0f / (one > 0.01f ? one : 0.01f));
+        for (int r = 0; r < nwarm; ++r) gemm();
+        CK(hipDeviceSynchronize());
+    }
+    const int reps = 200;
+    CK(hipEventRecord(e0));
+    for (int r = 0; r < reps; ++r) gemm();
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms_g = 0;
+    CK(hipEventElapsedTime(&ms_g, e0, e1));
+    const double us_g = ms_g * 1e3 / reps, flop = 2.0 * sh.batch * sh.M * (double)sh.N * sh.K;
+    std::vector<unsigned long long> hc(2 * (size_t)n_full);
+    CK(hipMemcpy(hc.data(), dclk, 16 * (size_t)n_full, hipMemcpyDeviceToHost));
+    // mixed load: the GEMM between HBM-bound kernels (3 x 0.25 ms of streaming per GEMM), as inside a batch of the pipeline
+    double us_mix = 0, ghz_mix = 0;
+    if (getenv("UB_MIX")) {
+        static f32x4* big = nullptr;
+        const size_t nbig = (size_t)96 << 20;                      // 1.5 GiB
+        if (!big) { CK(hipMalloc(&big, nbig * 16)); CK(hipMemset(big, 0, nbig * 16)); }
+        const int nmix = 150;
+        std::vector<hipEvent_t> ev(2 * nmix);
+        for (auto& e : ev) CK(hipEventCreate(&e));
+        for (int r = 0; r < nmix + 100; ++r) {
+            for (int q = 0; q < 3; ++q) hipLaunchKernelGGL(k_stream, dim3(ncu * 8), dim3(256), 0, 0, big, (float*)dOut, nbig);
+            if (r >= 100) CK(hipEventRecord(ev[2 * (r - 100)]));
+            gemm();
+            if (r >= 100) CK(hipEventRecord(ev[2 * (r - 100) + 1]));
+        }
+        CK(hipDeviceSynchronize());
+        for (int r = 0; r < nmix; ++r) { float ms = 0; CK(hipEventElapsedTime(&ms, ev[2 * r], ev[2 * r + 1])); us_mix += ms * 1e3 / nmix; }
+        std::vector<unsigned long long> hm(2 * (size_t)n_full);
+        CK(hipMemcpy(hm.data(), dclk, 16 * (size_t)n_full, hipMemcpyDeviceToHost));
+        for (int b = 0; b < n_full; ++b) ghz_mix += (double)hm[2 * b] / (double)hm[2 * b + 1] * 0.1 / n_full;
+        for (auto& e : ev) CK(hipEventDestroy(e));
+        gemm();
+        CK(hipDeviceSynchronize());
+    }
+    std::vector<float> hOut((size_t)sh.batch * sh.M * sh.N);
+    CK(hipMemcpy(hOut.data(), dOut, hOut.size() * 4, hipMemcpyDeviceToHost));
+    double maxref = 0, maxerr = 0;
+    const int bs[2] = {0, sh.batch - 1};
+    for (int bi = 0; bi < (sh.batch > 1 ? 2 : 1); ++bi)
+        for (int mi = 0; mi < 24; ++mi) {
+            const int b = bs[bi], m = mi < 4 ? sh.M - 1 - mi : (int)(((long)mi * 2654435761u) % sh.M);     // incl. rows of the last (tail) tiles
+            for (int n = 0; n < sh.N; n += 3) {
+                double a = 0;
+                const float* xr = &hX[((size_t)b * sh.M + m) * sh.K];
+                const float* wr = &hW[((size_t)b * sh.N + n) * sh.K];
+                for (int k = 0; k < sh.K; ++k) a += (double)xr[k] * (double)wr[k];
+                maxref = fmax(maxref, fabs(a)); maxerr = fmax(maxerr, fabs((double)hOut[((size_t)b * sh.M + m) * sh.N + n] - a));
+            }
+        }
+    double cyc = 0, ghz = 0;
+    for (int b = 0; b < n_full; ++b) { cyc += (double)hc[2 * b]; ghz += (double)hc[2 * b] / (double)hc[2 * b + 1] * 0.1; }
+    cyc /= n_full; ghz /= n_full;
+    const double ideal = 9.0 * FA * FB * 16.0 * occ * (NW / 4);
+    printf("  v2 tile %3dx%-3d %d waves NS=%d sched %d  %d wg/CU  %5d tiles = %d whole + %d x %d slabs | gemm %7.1f us = %6.1f TF-eq | vs library %.0f us: %.2fx"
+           " | %.0f cyc/step (ratio %.2f) %.2f GHz | err %.2e\n",
+           BN, BM, NW, NS, SCHED, occ, tiles, n_full, rem, split, us_g, flop / us_g * 1e-6, sh.yard_us, sh.yard_us / us_g, cyc / nkb, cyc / nkb / ideal, ghz,
+           maxerr / maxref);
+    if (us_mix > 0) printf("      between HBM-bound kernels (75 %% of the time streaming): gemm %7.1f us = %.2fx the library's, in-kernel clock %.2f GHz\n", us_mix, sh.yard_us / us_mix, ghz_mix);
     fflush(stdout);
 }
 
@@ -371,6 +670,14 @@ int main(int argc, char** argv) {
         const size_t padW = (size_t)sh.batch * (sh.N + 256) * sh.K * 6, padX = (size_t)sh.batch * (sh.M + 256) * sh.K * 6;
         CK(hipMalloc(&wP, padW)); CK(hipMalloc(&xP, padX));
         CK(hipMemcpy(dW, hW.data(), hW.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dX, hX.data(), hX.size() * 4, hipMemcpyHostToDevice));
+        if (argc > 2) {
+            run_gemm2<4, 2, 2, 2, 2, 0>(sh, dW, dX, wP, xP, dOut, hW, hX, ncu, false);
+            run_gemm2<4, 2, 2, 2, 2, 0>(sh, dW, dX, wP, xP, dOut, hW, hX, ncu, true);
+            run_gemm2<4, 2, 2, 4, 2, 0>(sh, dW, dX, wP, xP, dOut, hW, hX, ncu, true);
+            run_gemm2<4, 4, 2, 2, 3, 0>(sh, dW, dX, wP, xP, dOut, hW, hX, ncu, true);
+            CK(hipFree(dW)); CK(hipFree(dX)); CK(hipFree(dOut)); CK(hipFree(wP)); CK(hipFree(xP));
+            continue;
+        }
         run_gemm<2, 2, 2, 9>(sh, dW, dX, wP, xP, dOut, hW, hX, ncu);
         run_gemm<4, 4, 2, 9>(sh, dW, dX, wP, xP, dOut, hW, hX, ncu);
         run_gemm<4, 4, 3, 9>(sh, dW, dX, wP, xP, dOut, hW, hX, ncu);
