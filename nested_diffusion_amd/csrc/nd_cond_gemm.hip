@@ -1,6 +1,7 @@
 // nd_cond_gemm.hip -- the LDS-tiled large-M ConditionalLinear kernels (design notes: nd_cond_gemm.hpp).  gfx950 only.
 // Built with -mllvm -amdgpu-mfma-vgpr-form (nested_diffusion_amd/build.py).
 #include "nd_cond_gemm.hpp"
+#include "nd_b9.hpp"
 
 // which 128 x 128 tile a workgroup owns, and (slab >= 0) which k-slab of it
 struct CondGemmTile { int member, tm, tn, slab, rem_index; };
@@ -33,25 +34,26 @@ __device__ __forceinline__ CondGemmTile cg_decode(int bid, int n_full, int split
 //           fragment.  out_packed 0: row-major.
 //   MODE 1: the same v is not stored; part[m, c, 2*tn + wn] = sum over the wave's 64 columns of pw[c, n] * v  (lin3 +
 //           unetnorm3 + softplus + lin4, latent_model.py:181-184); summed r -> i in-lane, then across the 4 lane groups.
-template <int MODE>
-__device__ __forceinline__ void cg_epilogue(f32x4 (&acc)[4][4], const SkinnyDesc& d, int M, int t, int tm, int tn, int wn, int wm,
-                                            int lane, int ntl) {
+template <int MODE, int FI, int FJ>
+__device__ __forceinline__ void cg_epilogue_g(f32x4 (&acc)[FI][FJ], const SkinnyDesc& d, int M, int t, int nf0, int mf0, int pcol, int lane,
+                                              int ntl) {
+    // acc[i][j] = D of (n-fragment nf0 + i, m-fragment mf0 + j); FI fragments = the 64 output columns of one eps partial (pcol)
     const int N = d.N, nfr = (N + 15) >> 4, mfr = (M + 15) >> 4;
     const int g = lane >> 4, li = lane & 15;
-    float sc[4][4], sh[4][4];
+    float sc[FI][4], sh[FI][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < FI; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int n = min((tn * CG_F + wn * 4 + i) * 16 + 4 * g + r, N - 1);
+            const int n = min((nf0 + i) * 16 + 4 * g + r, N - 1);
             sc[i][r] = d.scale ? nd_ldg(d.scale + (size_t)t * N + n) : 1.0f;
             sh[i][r] = d.shift ? nd_ldg(d.shift + (size_t)t * N + n) : 0.0f;
         }
     const int act = d.act;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < FI; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < FJ; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float u = sc[i][r] * acc[i][j][r] + sh[i][r];
@@ -59,14 +61,17 @@ __device__ __forceinline__ void cg_epilogue(f32x4 (&acc)[4][4], const SkinnyDesc
             }
     if (MODE == 0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int nf = tn * CG_F + wn * 4 + i;
+        for (int i = 0; i < FI; ++i) {
+            const int nf = nf0 + i;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int mf = tm * CG_F + wm * 4 + j;
+            for (int j = 0; j < FJ; ++j) {
+                const int mf = mf0 + j;
                 if (nf < nfr && mf < mfr) {
                     const int n0 = nf * 16 + 4 * g, m = mf * 16 + li;
-                    if (d.out_packed) {
+                    if (d.out_packed == 3) {
+                        // frag32b3 image of [M][N] (csrc/nd_b9.hpp): the operand form of the next block on the bf16 matrix pipe
+                        if (m < M) nd_b9_store4(reinterpret_cast<bf16x8*>(d.out), N >> 5, m, n0, acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+                    } else if (d.out_packed) {
                         f32x4 v = acc[i][j];
 #pragma unroll
                         for (int r = 0; r < 4; ++r) if (n0 + r >= N) v[r] = 0.f;
@@ -85,28 +90,34 @@ __device__ __forceinline__ void cg_epilogue(f32x4 (&acc)[4][4], const SkinnyDesc
     } else {
         const int C = d.C;
         for (int c = 0; c < C; ++c) {
-            float pw[4][4];
+            float pw[FI][4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < FI; ++i)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int n = (tn * CG_F + wn * 4 + i) * 16 + 4 * g + r;
+                    const int n = (nf0 + i) * 16 + 4 * g + r;
                     pw[i][r] = n < N ? nd_ldg(d.pw + (size_t)c * N + n) : 0.0f;
                 }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < FJ; ++j) {
                 float s = 0.f;
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < FI; ++i)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) s += pw[i][r] * acc[i][j][r];
                 s += __shfl_xor(s, 16, 64);
                 s += __shfl_xor(s, 32, 64);
-                const int m = (tm * CG_F + wm * 4 + j) * 16 + li;
-                if (g == 0 && m < M) *(__attribute__((address_space(1))) float*)(d.part + ((size_t)m * C + c) * ntl + tn * 2 + wn) = s;
+                const int m = (mf0 + j) * 16 + li;
+                if (g == 0 && m < M) *(__attribute__((address_space(1))) float*)(d.part + ((size_t)m * C + c) * ntl + pcol) = s;
             }
         }
     }
+}
+
+template <int MODE>
+__device__ __forceinline__ void cg_epilogue(f32x4 (&acc)[4][4], const SkinnyDesc& d, int M, int t, int tm, int tn, int wn, int wm,
+                                            int lane, int ntl) {
+    cg_epilogue_g<MODE, 4, 4>(acc, d, M, t, tn * CG_F + wn * 4, tm * CG_F + wm * 4, tn * 2 + wn, lane, ntl);
 }
 
 __device__ __forceinline__ const float* cg_uniform_ptr(const float* p) {
@@ -257,6 +268,93 @@ __global__ __launch_bounds__(64) void k_cond_gemm_fixup(SkinnyDesc d0, const Ski
             for (int j = 0; j < 4; ++j)
                 acc[i][j] += *(const __attribute__((address_space(1))) f32x4*)(pt + (size_t)k * (CG_T * CG_T) + (i * 4 + j) * 256);
     cg_epilogue<MODE>(acc, d, M, t, tm, tn, wn, wm, lane, 2 * TN);
+}
+
+// ---- the same blocks on the bf16 matrix pipe with exact fp32 products (csrc/nd_b9.hpp) ---------------------------------------------
+// Operands as frag32b3 images: d.w = image of the layer's [N][K] weight (made at nd_load_member), d.x = image of the [M][K]
+// activations (written by the step head / by MODE 0 of this kernel: out_packed 3).  8 waves per 128 x 128 tile (2 over the columns x 4
+// over the rows, 64 x 32 each), one workgroup per CU, 96 KiB LDS ring of two K-steps of 32; tile list, XCD dealing, k-split tail
+// and epilogues exactly as k_cond_gemm.  Measured (tools/ubench_bf16x9.hip, K = 5 members x 640 rows): 600-630 us per launch
+// against 800-810 us for the f32-input MFMA form.
+#define CG9_FA 4
+#define CG9_FB 2
+#define CG9_WN 2
+#define CG9_WM 4
+#define CG9_NS 2
+template <int MODE>
+__global__ __launch_bounds__(512) void k_cond_gemm_b9(SkinnyDesc d0, const SkinnyDesc* __restrict__ table, int M, int t, int TM, int TN,
+                                                      int n_full, int split, float* __restrict__ ws) {
+    constexpr int NW = CG9_WN * CG9_WM, NPC = (CG9_WN * CG9_FA + CG9_WM * CG9_FB) * 3, NP = (NPC + NW - 1) / NW;
+    extern __shared__ __attribute__((aligned(16))) bf16x8 lds9[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave / CG9_WM, wm = wave % CG9_WM;
+    const CondGemmTile tl = cg_decode(blockIdx.x, n_full, split, TM, TN);
+    const SkinnyDesc d = table ? table[tl.member] : d0;
+    const int K = __builtin_amdgcn_readfirstlane(d.K), N = __builtin_amdgcn_readfirstlane(d.N);
+    const int nkb = K >> 5, nfr = (N + 15) >> 4, mfr = (M + 15) >> 4;
+    const int c0 = tl.slab < 0 ? 0 : (int)((long)tl.slab * nkb / split);
+    const int c1 = tl.slab < 0 ? nkb : (int)((long)(tl.slab + 1) * nkb / split);
+    const bf16x8* wbase = reinterpret_cast<const bf16x8*>(cg_uniform_ptr(d.w));
+    const bf16x8* xbase = reinterpret_cast<const bf16x8*>(cg_uniform_ptr(d.x));
+    const bf16x8* src[NP];
+#pragma unroll
+    for (int u = 0; u < NP; ++u) {
+        const int e = min(wave * NP + u, NPC - 1), f = e / 3, pl = e % 3;
+        const bf16x8* base = f < CG_F ? wbase + ((size_t)min(tl.tn * CG_F + f, nfr - 1) * nkb + c0) * B9_BLOCK_UNITS
+                                      : xbase + ((size_t)min(tl.tm * CG_F + f - CG_F, mfr - 1) * nkb + c0) * B9_BLOCK_UNITS;
+        src[u] = base + pl * 64 + lane;
+    }
+    f32x4 acc[CG9_FA][CG9_FB];
+#pragma unroll
+    for (int i = 0; i < CG9_FA; ++i)
+#pragma unroll
+        for (int j = 0; j < CG9_FB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    b9_mainloop<CG9_FA, CG9_FB, CG9_WN, CG9_WM, CG9_NS>(acc, src, lds9, c1 - c0, wave, wn, wm, lane);
+    if (tl.slab >= 0) {     // [remainder tile][slab][wave][fragment][lane]: 8 waves x 8 fragments x 1 KiB = one 128 x 128 fp32 tile
+        float* pt = ws + ((size_t)tl.rem_index * split + tl.slab) * (CG_T * CG_T) + (size_t)wave * (CG9_FA * CG9_FB) * 256 + lane * 4;
+#pragma unroll
+        for (int i = 0; i < CG9_FA; ++i)
+#pragma unroll
+            for (int j = 0; j < CG9_FB; ++j) *(__attribute__((address_space(1))) f32x4*)(pt + (i * CG9_FB + j) * 256) = acc[i][j];
+        return;
+    }
+    cg_epilogue_g<MODE, CG9_FA, CG9_FB>(acc, d, M, t, tl.tn * CG_F + wn * CG9_FA, tl.tm * CG_F + wm * CG9_FB, tl.tn * 2 + wn, lane, 2 * TN);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(64) void k_cond_gemm_b9_fixup(SkinnyDesc d0, const SkinnyDesc* __restrict__ table, int M, int t, int TM,
+                                                           int TN, int n_full, int split, const float* __restrict__ ws) {
+    constexpr int NW = CG9_WN * CG9_WM;
+    const int lane = threadIdx.x, wave = blockIdx.x % NW, ri = blockIdx.x / NW;
+    const int wn = wave / CG9_WM, wm = wave % CG9_WM;
+    const int bid = n_full + ri, per = TM * TN;
+    const int member = bid / per, r2 = bid - member * per, tn = r2 / TM, tm = r2 - tn * TM;
+    const SkinnyDesc d = table ? table[member] : d0;
+    const float* pt = ws + (size_t)ri * split * (CG_T * CG_T) + (size_t)wave * (CG9_FA * CG9_FB) * 256 + lane * 4;
+    f32x4 acc[CG9_FA][CG9_FB];
+#pragma unroll
+    for (int i = 0; i < CG9_FA; ++i)
+#pragma unroll
+        for (int j = 0; j < CG9_FB; ++j) acc[i][j] = *(const __attribute__((address_space(1))) f32x4*)(pt + (i * CG9_FB + j) * 256);
+#pragma unroll 2
+    for (int k = 1; k < split; ++k)
+#pragma unroll
+        for (int i = 0; i < CG9_FA; ++i)
+#pragma unroll
+            for (int j = 0; j < CG9_FB; ++j)
+                acc[i][j] += *(const __attribute__((address_space(1))) f32x4*)(pt + (size_t)k * (CG_T * CG_T) + (i * CG9_FB + j) * 256);
+    cg_epilogue_g<MODE, CG9_FA, CG9_FB>(acc, d, M, t, tn * CG_F + wn * CG9_FA, tm * CG_F + wm * CG9_FB, tn * 2 + wn, lane, 2 * TN);
+}
+
+size_t nd_cond_gemm_b9_dynlds() { return (size_t)CG9_NS * (CG9_WN * CG9_FA + CG9_WM * CG9_FB) * 3 * 1024; }
+void* nd_cond_gemm_b9_kernel(int mode) { return mode == 1 ? (void*)k_cond_gemm_b9<1> : (void*)k_cond_gemm_b9<0>; }
+void* nd_cond_gemm_b9_fixup_kernel(int mode) { return mode == 1 ? (void*)k_cond_gemm_b9_fixup<1> : (void*)k_cond_gemm_b9_fixup<0>; }
+// dynamic LDS above 64 KiB has to be allowed per kernel and device before the first launch (graph kernel nodes included)
+hipError_t nd_cond_gemm_b9_prepare() {
+    hipError_t e = hipFuncSetAttribute((const void*)k_cond_gemm_b9<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nd_cond_gemm_b9_dynlds());
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute((const void*)k_cond_gemm_b9<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nd_cond_gemm_b9_dynlds());
 }
 
 // Staging depth 3: 48 KiB of LDS and 160 VGPRs per workgroup, three workgroups resident per CU.  Measured at M = 640, K = 5

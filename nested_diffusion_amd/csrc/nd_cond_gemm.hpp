@@ -84,3 +84,11 @@ size_t nd_cond_gemm_dynlds();                 // dynamic LDS bytes of the launch
 // d0 / table as nd_launch_skinny.  ws: >= plan.ws_bytes (may be null when plan.rem == 0).
 hipError_t nd_launch_cond_gemm(int mode, const CondGemmPlan& p, SkinnyDesc d0, const SkinnyDesc* table, int M, int t, float* ws,
                                hipStream_t st);
+
+// The same blocks on the bf16 matrix pipe with exact fp32 products (frag32b3 operands, csrc/nd_b9.hpp): same argument list, same
+// plan (tile list, n_full / split, workspace); launch with 512 threads and nd_cond_gemm_b9_dynlds() bytes of dynamic LDS after one
+// nd_cond_gemm_b9_prepare() per device; fixup: rem * 8 workgroups of 64.
+void* nd_cond_gemm_b9_kernel(int mode);
+void* nd_cond_gemm_b9_fixup_kernel(int mode);
+size_t nd_cond_gemm_b9_dynlds();
+hipError_t nd_cond_gemm_b9_prepare();

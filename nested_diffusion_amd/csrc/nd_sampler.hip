@@ -7,6 +7,7 @@
 //   diffusion/latent_model.py:93-105,169-184  ConditionalLinear / ConditionalModel.forward
 #include "nd_common.hpp"
 #include "nd_cond_gemm.hpp"
+#include "nd_b9.hpp"
 #include "nd_rng.hpp"
 #include "../../include/nested_diffusion.h"
 
@@ -17,6 +18,7 @@
 #include <cstdio>
 #include <cstdarg>
 #include <cstring>
+#include <cstdlib>
 
 // ---------------------------------------------------------------------------------------------
 // error plumbing
@@ -58,7 +60,8 @@ struct MemberDev {
     float* h1;             // frag16 [M, F]
     float* ybuf;           // [2, maxM, C]
     const float* epart;    // [M, C, NT]
-    int h16;               // 1: h1 is written as frag32h fp16
+    int h16;               // layout h1 is written in: 0 frag16 fp32, 1 frag32h fp16, 2 frag32b3 (three bf16 pieces per value, csrc/nd_b9.hpp:
+                           // the input of the lin2 block on the bf16 matrix pipe; h1 then points at that image)
 };
 
 #define ND_MAX_C 8
@@ -220,7 +223,9 @@ __global__ __launch_bounds__(256) void k_step_head(MemberInline mi, const Member
     h.y = nd_softplus(a.y * u[1] + cc.y) * xe.y;
     h.z = nd_softplus(a.z * u[2] + cc.z) * xe.z;
     h.w = nd_softplus(a.w * u[3] + cc.w) * xe.w;
-    if (mb.h16)
+    if (mb.h16 == 2)
+        nd_b9_store4(reinterpret_cast<bf16x8*>(mb.h1), F >> 5, m, n, h.x, h.y, h.z, h.w);
+    else if (mb.h16)
         *(__attribute__((address_space(1))) f16x4*)(reinterpret_cast<_Float16*>(mb.h1) + nd_pkh(m, n, F >> 5)) =
             f16x4{(_Float16)h.x, (_Float16)h.y, (_Float16)h.z, (_Float16)h.w};
     else
@@ -320,7 +325,8 @@ __global__ void k_fold_steps(float* A, float* Cc, const float* emb, const float*
 // host handle
 // ---------------------------------------------------------------------------------------------
 #define ND_KEEP_BYTES 208.0e6     // weights kept Infinity-Cache resident across steps (see nd_load_member)
-enum { L_ENC0 = 0, L_ENC1 = 1, L_ENC2 = 2, L_LIN2 = 3, L_LIN3 = 4, L_COUNT = 5 };
+// L_LIN2S / L_LIN3S: the two step blocks with frag32b3 operands (bf16 matrix pipe, exact fp32 products: rows > 128 only)
+enum { L_ENC0 = 0, L_ENC1 = 1, L_ENC2 = 2, L_LIN2 = 3, L_LIN3 = 4, L_LIN2S = 5, L_LIN3S = 6, L_COUNT = 7 };
 
 struct MemberHost {
     bool loaded = false;
@@ -329,6 +335,7 @@ struct MemberHost {
     float *w_enc0, *w_enc3, *w_enc6, *w_lin2, *w_lin3;   // frag16-packed weights
     float *w_lin1, *w_lin4, *b_lin4;                      // small row-major copies
     float *e0, *e1, *xe, *ybuf, *h1, *h2, *epart, *splitk;
+    void *w_lin2s = nullptr, *w_lin3s = nullptr, *h1s = nullptr, *h2s = nullptr;   // frag32b3 images (handles with max_rows > 128, fp32)
 };
 
 struct GraphKey {
@@ -369,6 +376,7 @@ struct nd_handle_s {
     float *alphas = nullptr, *omabs = nullptr;
     float* xpack = nullptr;                // frag16 [maxB][D] image batch shared by all members
     float* tile_ws = nullptr;              // k-slab accumulators of k_cond_gemm's split tail (large-M steps only)
+    bool b9 = false;                       // the large-M step blocks run on the bf16 matrix pipe (frag32b3 copies of lin2 / lin3 exist)
     unsigned long long* rng_state = nullptr;   // {seed, batch counter | first image << 32} of the in-library noise (nd_seed)
     float* noise_ws = nullptr;             // [K][T][max_rows][C] draws of the in-library noise (noise_dev == NULL)
     float* logits_ws = nullptr;            // [K][max_batch][C] guiding-prediction logits of nd_predict_batch
@@ -419,6 +427,9 @@ static void carve(nd_handle_s* h, char* base, size_t* total) {
     h->logits_ws = cv.take<float>(K * mB * C);
     h->xpack = cv.take<float>(pB * D);
     h->tile_ws = cv.take<float>(nd_cond_gemm_wanted((int)mM, h->half) ? (size_t)CG_MAX_SLABS * CG_T * CG_T : 1);
+    // more than 128 rows per member and fp32: the step blocks are MFMA-bound GEMMs; they run on the bf16 matrix pipe with exact
+    // fp32 products when the depth allows (F % 32 == 0), which takes a frag32b3 copy of lin2 / lin3 (1.5 x their fp32 size)
+    h->b9 = nd_cond_gemm_wanted((int)mM, h->half) && (F % 32) == 0 && !getenv("ND_STEP_F32_MFMA");
     for (size_t k = 0; k < K; ++k) {
         MemberHost& m = h->members[k];
         m.sc0 = cv.take<float>(H); m.sh0 = cv.take<float>(H);
@@ -431,6 +442,10 @@ static void carve(nd_handle_s* h, char* base, size_t* total) {
         m.e0 = cv.take<float>(pB * H); m.e1 = cv.take<float>(pB * H); m.xe = cv.take<float>(pB * F);
         m.ybuf = cv.take<float>(2 * mM * C);
         m.h1 = cv.take<float>(pM * F); m.h2 = cv.take<float>(pM * F);
+        if (h->b9) {
+            m.w_lin2s = cv.take<char>(nd_b9_bytes((int)F, (int)F)); m.w_lin3s = cv.take<char>(nd_b9_bytes((int)F, (int)F));
+            m.h1s = cv.take<char>(nd_b9_bytes((int)pM, (int)F)); m.h2s = cv.take<char>(nd_b9_bytes((int)pM, (int)F));
+        }
         // eps partials per (row, class): F/16 from k_skinny, 2 per 128-column tile from k_cond_gemm (more than F/16 when F = 16)
         const size_t ntl_max = nd_cond_gemm_wanted((int)mM, h->half) ? (size_t)nd_cond_gemm_plan((int)F, (int)F, (int)mM, 1, h->half).ntl : 0;
         m.epart = cv.take<float>(((size_t)h->NT > ntl_max ? (size_t)h->NT : ntl_max) * mM * C);
@@ -568,6 +583,12 @@ extern "C" int nd_load_member(nd_handle h, int k, const nd_member_weights* w, vo
     launch_pack(w->enc6_w, m.w_enc6, F, H, h->half, st);
     launch_pack(w->lin2_w, m.w_lin2, F, F, h->half, st);
     launch_pack(w->lin3_w, m.w_lin3, F, F, h->half, st);
+    if (h->b9) {
+        int rc = nd_split_rows(w->lin2_w, m.w_lin2s, F, F, st);
+        if (rc == ND_OK) rc = nd_split_rows(w->lin3_w, m.w_lin3s, F, F, st);
+        if (rc != ND_OK) return rc;
+        HIP_CHECK(nd_cond_gemm_b9_prepare());
+    }
     HIP_CHECK(hipMemcpyAsync(m.w_lin1, w->lin1_w, sizeof(float) * F * 2 * C, hipMemcpyDeviceToDevice, st));
     HIP_CHECK(hipMemcpyAsync(m.w_lin4, w->lin4_w, sizeof(float) * C * F, hipMemcpyDeviceToDevice, st));
     HIP_CHECK(hipMemcpyAsync(m.b_lin4, w->lin4_b, sizeof(float) * C, hipMemcpyDeviceToDevice, st));
@@ -581,6 +602,11 @@ extern "C" int nd_load_member(nd_handle h, int k, const nd_member_weights* w, vo
     ds[L_ENC2] = SkinnyDesc{m.e1, m.w_enc6, m.sc2, m.sh2, m.xe, nullptr, nullptr, H, F, C, ND_ACT_NONE, 1};
     ds[L_LIN2] = SkinnyDesc{m.h1, m.w_lin2, m.A[1], m.Cc[1], m.h2, nullptr, nullptr, F, F, C, ND_ACT_SOFTPLUS, opk};
     ds[L_LIN3] = SkinnyDesc{m.h2, m.w_lin3, m.A[2], m.Cc[2], nullptr, m.w_lin4, m.epart, F, F, C, ND_ACT_SOFTPLUS, 0};
+    ds[L_LIN2S] = ds[L_LIN2]; ds[L_LIN3S] = ds[L_LIN3];
+    if (h->b9) {   // the same two blocks on frag32b3 operands: h1s -> lin2 -> h2s (out_packed 3) -> lin3 + lin4 -> eps partials
+        ds[L_LIN2S].x = (const float*)m.h1s; ds[L_LIN2S].w = (const float*)m.w_lin2s; ds[L_LIN2S].out = (float*)m.h2s; ds[L_LIN2S].out_packed = 3;
+        ds[L_LIN3S].x = (const float*)m.h2s; ds[L_LIN3S].w = (const float*)m.w_lin3s;
+    }
     {
         // INFINITY-CACHE RESIDENCY.  A step streams 2 K F^2 weights (671 MB at K = 5, fp32), far more than the 256 MiB Infinity
         // Cache, so the step kernels read W with nontemporal loads -- nothing survives to the next step.  Reading the first
@@ -877,7 +903,16 @@ static hipError_t emit_loop(nd_handle_s* h, Emitter& em, int m0, int nm, StepIO 
     // more than 128 rows: the LDS-tiled kernel (+ its fixup for the k-split tail) takes the place of each k_skinny node
     CondGemmPlan tp = nd_cond_gemm_plan(F, F, M, nm, h->half);
     float* tws = h->tile_ws;
-    const dim3 tgrid((unsigned)(tp.n_full + tp.rem * tp.split)), tfix((unsigned)tp.rem * 4);
+    // ... on the bf16 matrix pipe (frag32b3 operands, exact fp32 products) where the handle holds the images: the step head then
+    // writes h1 as such an image (its record travels by value, so the layout is chosen per launch; the device-table path of more
+    // than ND_INLINE_DESCS members keeps the f32-input MFMA kernel)
+    const bool b9 = tp.use_tile && h->b9 && inl;
+    if (b9) {
+        t2 = h->descs_dev + (size_t)L_LIN2S * K + m0;
+        t3 = h->descs_dev + (size_t)L_LIN3S * K + m0;
+        for (int g = 0; g < nm; ++g) { mi.m[g].h1 = (float*)h->members[m0 + g].h1s; mi.m[g].h16 = 2; }
+    }
+    const dim3 tgrid((unsigned)(tp.n_full + tp.rem * tp.split)), tfix((unsigned)tp.rem * (b9 ? 8 : 4));
     // probes: up to 8 steps spread over the loop (never step 0: its head is the cheap INIT form)
     const int want = h->profiling ? (T - 1 < 8 ? T - 1 : 8) : 0;
     const int stride = want > 0 ? (T - 1) / want : 0;
@@ -898,11 +933,18 @@ static hipError_t emit_loop(nd_handle_s* h, Emitter& em, int m0, int nm, StepIO 
         if (probe) em.record(ev[1]);
         if (tp.use_tile) {
             void* a2[] = {&d0, &t2, &M, &t, &tp.TM, &tp.TN, &tp.n_full, &tp.split, &tws};
-            em.emit(nd_cond_gemm_kernel(0), tgrid, dim3(256), a2, nd_cond_gemm_dynlds());
-            if (tp.rem > 0) em.emit(nd_cond_gemm_fixup_kernel(0), tfix, dim3(64), a2);
             void* a3[] = {&d0, &t3, &M, &t, &tp.TM, &tp.TN, &tp.n_full, &tp.split, &tws};
-            em.emit(nd_cond_gemm_kernel(1), tgrid, dim3(256), a3, nd_cond_gemm_dynlds());
-            if (tp.rem > 0) em.emit(nd_cond_gemm_fixup_kernel(1), tfix, dim3(64), a3);
+            if (b9) {
+                em.emit(nd_cond_gemm_b9_kernel(0), tgrid, dim3(512), a2, nd_cond_gemm_b9_dynlds());
+                if (tp.rem > 0) em.emit(nd_cond_gemm_b9_fixup_kernel(0), tfix, dim3(64), a2);
+                em.emit(nd_cond_gemm_b9_kernel(1), tgrid, dim3(512), a3, nd_cond_gemm_b9_dynlds());
+                if (tp.rem > 0) em.emit(nd_cond_gemm_b9_fixup_kernel(1), tfix, dim3(64), a3);
+            } else {
+                em.emit(nd_cond_gemm_kernel(0), tgrid, dim3(256), a2, nd_cond_gemm_dynlds());
+                if (tp.rem > 0) em.emit(nd_cond_gemm_fixup_kernel(0), tfix, dim3(64), a2);
+                em.emit(nd_cond_gemm_kernel(1), tgrid, dim3(256), a3, nd_cond_gemm_dynlds());
+                if (tp.rem > 0) em.emit(nd_cond_gemm_fixup_kernel(1), tfix, dim3(64), a3);
+            }
         } else {
             void* a2[] = {&i2, &s2, &nm, &M, &t, &cps2};
             em.emit(L2.fn, L2.grid, L2.block, a2);
