@@ -31,6 +31,7 @@ import torch  # noqa: E402
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s is the measured copy ceiling
 F32_MFMA_PEAK_TF = 157.3   # dense f32-input MFMA (v_mfma_f32_16x16x4_f32), same guide
 F16_MFMA_PEAK_TF = 2500.0  # dense f16 MFMA
+BF16_MFMA_PEAK_TF = 2500.0  # dense bf16 MFMA (same guide; AMD's 5 PF headline includes 2:1 sparsity)
 
 
 def ns(**kw):
@@ -376,12 +377,18 @@ def main():
         roof["co_limit_mfma_frac"] = (K * 2.0 * M * F * F / (avg_us * 1e-6) / 1e12 / F32_MFMA_PEAK_TF) if (n_probe and args.dtype == "f32") else None
         roof["traffic_source"] = why
     else:
-        # M = B*mc rows > 64: the blocks are compute-bound f32-MFMA GEMMs (2*M*F*F flop per member and launch)
+        # M = B*mc rows > 128: the blocks are compute-bound GEMMs (2*M*F*F flop per member and launch).  fp32 arithmetic runs on the
+        # bf16 matrix pipe with exact products (nine bf16 pair products per fp32 product, csrc/nd_b9.hpp): the peak for USEFUL fp32
+        # flop is then the dense bf16 peak / 9; the f32-input MFMA form (ND_STEP_F32_MFMA=1) has 157.3 TFLOP/s
         alg = K * 2.0 * M * F * F
         achieved = alg / (avg_us * 1e-6) / 1e12 if n_probe else None
-        peak = F32_MFMA_PEAK_TF if args.dtype == "f32" else F16_MFMA_PEAK_TF
+        b9 = args.dtype == "f32" and plan.get("b9")
+        peak = (BF16_MFMA_PEAK_TF / 9.0 if b9 else F32_MFMA_PEAK_TF) if args.dtype == "f32" else F16_MFMA_PEAK_TF
         roof = {"bound": "mfma", "kernel": plan["name"], "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                "frac": (achieved / peak) if achieved else None, "alg_flop_per_launch": alg}
+                "frac": (achieved / peak) if achieved else None, "alg_flop_per_launch": alg,
+                "label": ("useful fp32 TFLOP/s over (dense bf16 MFMA peak 2500 TFLOP/s) / 9: each fp32 product costs nine bf16 MFMA products; "
+                          f"the same launch is {achieved / F32_MFMA_PEAK_TF:.2f} of the 157.3 TFLOP/s f32-input MFMA peak it used to be priced against"
+                          if (b9 and achieved) else "fp32 TFLOP/s over the dense MFMA peak of the operand type")}
         roof["traffic"], roof["traffic_source"] = shape_traffic(args.dtype, M, K)
     roof["avg_launch_us"] = avg_us
     roof["probe"] = {"head_interval_us": head_us, "lin2_plus_lin3_interval_us": pair_us, "record_node_us": ovh_us, "steps_probed": n_probe,

@@ -37,16 +37,18 @@ def is_stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    if not force and not is_stale():
+def build(force: bool = False, verbose: bool = False, out: str = None, defines=()) -> str:
+    """out / defines: an experimental variant next to the product library (e.g. defines=["ND_SKINNY_B9=1"], out=".../libnd_hip_x.so";
+    loaded with ND_LIB_PATH=<that file>)."""
+    if out is None and not defines and not force and not is_stale():
         return LIB
     hipcc = _hipcc()
-    objdir = os.path.join(HERE, "build")
+    objdir = os.path.join(HERE, "build" if out is None else "build_" + os.path.basename(out).replace(".", "_"))
     os.makedirs(objdir, exist_ok=True)
 
     def cc(src):
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
-        cmd = [hipcc, *FLAGS, *EXTRA_FLAGS.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc, *FLAGS, *["-D" + d for d in defines], *EXTRA_FLAGS.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr}")
@@ -56,10 +58,11 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
     with ThreadPoolExecutor(max_workers=8) as ex:
         objs = list(ex.map(cc, SOURCES))
-    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs], capture_output=True, text=True)
+    target = out or LIB
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", target, *objs], capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stderr}")
-    return LIB
+    return target
 
 
 if __name__ == "__main__":

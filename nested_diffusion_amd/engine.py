@@ -4,6 +4,7 @@ libnd_hip.so.  PyTorch is plumbing here -- all arithmetic of the hot path runs i
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, Optional, Sequence, Tuple
 
 import torch
@@ -179,9 +180,14 @@ class EnsembleEngine:
         n_members = self.K if n_members is None else n_members
         check(self.lib.nd_step_plan(self.F, int(M), int(n_members), self.dtype, out), "nd_step_plan")
         tile = bool(out[0])
-        name = ("k_cond_gemm<{0,1}> (LDS-tiled 128x128 f32-MFMA ConditionalLinear blocks, K members per launch)" if tile else
+        # the tiled blocks run on the bf16 matrix pipe with exact fp32 products where the library keeps frag32b3 copies of lin2 / lin3
+        # (fp32 handles with F % 32 == 0 and at most 8 members per launch; ND_STEP_F32_MFMA=1 keeps the f32-input MFMA kernel)
+        b9 = tile and self.dtype == _lib.ND_DTYPE_F32 and self.F % 32 == 0 and n_members <= 8 and not os.environ.get("ND_STEP_F32_MFMA")
+        name = (("k_cond_gemm_b9<{0,1}> (LDS-tiled 128x128 ConditionalLinear blocks on the bf16 matrix pipe, nine exact bf16 pair products "
+                 "per fp32 product, K members per launch)" if b9 else
+                 "k_cond_gemm<{0,1}> (LDS-tiled 128x128 f32-MFMA ConditionalLinear blocks, K members per launch)") if tile else
                 "k_skinny<MT,NF,4,U,{0,1}> (weight-streaming lin2 / lin3+lin4 ConditionalLinear blocks, K members per launch)")
-        return {"kernel": "k_cond_gemm" if tile else "k_skinny", "name": name, "workgroups": out[1], "whole_tiles": out[2],
+        return {"kernel": "k_cond_gemm" if tile else "k_skinny", "b9": bool(b9), "name": name, "workgroups": out[1], "whole_tiles": out[2],
                 "remainder_tiles": out[3], "split": out[4], "partials": out[5], "TM": out[6], "TN": out[7]}
 
     def static_buffers(self, n_members: int, B: int, mc: int, T: int, seq: bool) -> Dict[str, torch.Tensor]:

@@ -191,6 +191,37 @@ def layernorm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: fl
     return out
 
 
+def layernorm_split(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float) -> SplitMatrix:
+    """LayerNorm with its result written as a frag32b3 image (the input of the gemm_split that follows it in a ViT block)."""
+    x = _f32(x, "x")
+    dim = x.shape[-1]
+    rows = x.numel() // dim
+    out = SplitMatrix(rows, dim, x.device)
+    check(_lib.load().nd_layernorm_split(ptr(x), ptr(_f32(weight, "weight")), ptr(_f32(bias, "bias")), ptr(out.data), rows, dim, float(eps),
+                                         _stream(x)), "nd_layernorm_split")
+    return out
+
+
+def attention_split(qkv: torch.Tensor, B: int, N: int, heads: int) -> SplitMatrix:
+    """fp32 attention with its [B*N, heads*64] result written as a frag32b3 image (the input of the proj gemm_split)."""
+    qkv = _f32(qkv, "qkv")
+    d = qkv.shape[-1] // (3 * heads)
+    if qkv.numel() != B * N * 3 * heads * d:
+        raise ValueError("qkv has the wrong number of elements")
+    out = SplitMatrix(B * N, heads * d, qkv.device)
+    check(_lib.load().nd_attention_split(ptr(qkv), ptr(out.data), B, N, heads, d, _stream(qkv)), "nd_attention_split")
+    return out
+
+
+def patchify_split(img: torch.Tensor, p: int) -> SplitMatrix:
+    """im2col written as the frag32b3 image of [B*(H/p)*(W/p), Cin*p*p] (the input of the patch-embedding gemm_split)."""
+    img = _f32(img, "img")
+    B, Cin, H, W = img.shape
+    out = SplitMatrix(B * (H // p) * (W // p), Cin * p * p, img.device)
+    check(_lib.load().nd_patchify_split(ptr(img), ptr(out.data), B, Cin, H, W, p, _stream(img)), "nd_patchify_split")
+    return out
+
+
 def attention(qkv: torch.Tensor, B: int, N: int, heads: int, dtype="f32") -> torch.Tensor:
     """qkv: [B*N, 3*heads*64] (output of the qkv Linear) -> [B*N, heads*64].  dtype 'f16': fp16-operand contractions."""
     lib = _lib.load()

@@ -129,6 +129,28 @@ def test_gemm_split_exact_products_on_the_bf16_pipe(M, K, N, act, res):
         assert torch.equal(ops.join_rows(only), out)
 
 
+@pytest.mark.parametrize("rows,dim", [(6272, 768), (5, 768), (70, 1024), (100, 2048), (64, 64), (6257, 128)])
+def test_layernorm_split_is_the_layernorm(rows, dim):
+    """nd_layernorm_split (both forms: 16 rows per workgroup through LDS, and the direct one) writes exactly nd_layernorm's values;
+    rows of the last 16-row block past `rows` read back as zeros in the LDS form."""
+    from nested_diffusion_amd import ops
+    g = torch.Generator().manual_seed(rows + dim)
+    x = (torch.randn(rows, dim, generator=g) * 3 + 1).cuda()
+    w, b = torch.randn(dim, generator=g).cuda(), torch.randn(dim, generator=g).cuda()
+    assert torch.equal(ops.join_rows(ops.layernorm_split(x, w, b, 1e-6)), ops.layernorm(x, w, b, 1e-6))
+
+
+def test_attention_and_patchify_split_outputs_are_exact():
+    from nested_diffusion_amd import ops
+    g = torch.Generator().manual_seed(3)
+    for B, N, heads in ((3, 196, 12), (2, 5, 2), (1, 197, 12)):
+        qkv = torch.randn(B * N, 3 * heads * 64, generator=g).cuda()
+        assert torch.equal(ops.join_rows(ops.attention_split(qkv, B, N, heads)), ops.attention(qkv, B, N, heads))
+    for B, C, H, p in ((3, 3, 224, 16), (2, 3, 32, 16), (1, 2, 16, 8), (2, 2, 16, 4), (5, 3, 48, 16)):     # p = 4: element-wise form
+        img = torch.rand(B, C, H, H, generator=g).cuda()
+        assert torch.equal(ops.join_rows(ops.patchify_split(img, p)), ops.patchify(img, p))
+
+
 def test_gemm_split_argument_checks():
     from nested_diffusion_amd import _lib, ops
     lib = _lib.load()

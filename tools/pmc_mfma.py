@@ -12,7 +12,7 @@ import os
 import sys
 
 root = sys.argv[1]
-WANT = ("k_attention", "k_gemm_nt", "k_skinny", "k_cond_gemm", "k_step_head", "k_gemm_fixup", "k_layernorm")
+WANT = ("k_attention", "k_gemm_nt", "k_gemm_b9", "k_b9_fixup", "k_skinny", "k_cond_gemm", "k_step_head", "k_gemm_fixup", "k_layernorm")
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
     with open(f) as fh:
@@ -21,6 +21,9 @@ for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursiv
             if not any(w in k for w in WANT):
                 continue
             key = k.split("(")[0].replace("void ", "").strip()
+            if key.startswith("_Z9k_gemm_b9"):       # rocprofv3 leaves this one mangled: template arguments FA, FB, WN, WM, NS
+                import re
+                key = "k_gemm_b9<" + ", ".join(re.findall(r"Li(\d+)E", key)[:5]) + ">"
             acc[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
 failed = []
 fp = os.path.join(root, "failed_passes.txt")

@@ -1,9 +1,9 @@
 #!/bin/bash
 # MFMA-utilisation counters (rocprofv3 PMC, one counter group per pass, kernel-trace only -- never combined with --stats or
 # other trace domains) for the matrix-core kernels of the hot path:
-#   conditioner  (tools/bench_cond.py):          k_attention*, k_gemm_nt
+#   conditioner  (tools/bench_cond.py):          k_attention*, k_gemm_b9 (k_gemm_nt with ND_GEMM_F32=mfma_f32)
 #   sampler mc=1 (tools/bench_sampler.py 5 6 32 1):   k_skinny
-#   sampler mc=20 (tools/bench_sampler.py 5 4 32 20): k_cond_gemm
+#   sampler mc=20 (tools/bench_sampler.py 5 4 32 20): k_cond_gemm_b9 (k_cond_gemm with ND_STEP_F32_MFMA=1)
 # Run on the GPU box:  bash tools/pmc_mfma.sh      -> gpurun_out/pmc_mfma/{summary.csv, *.log}
 # A pass that fails makes the script fail (exit 1) after the remaining passes have run; the failure is named in summary.csv.
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_mfma
