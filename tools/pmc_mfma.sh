@@ -31,4 +31,6 @@ run_pass samp20_g1 "$G1" $GRAFT_REPO_ROOT/tools/bench_sampler.py 5 4 32 20
 run_pass samp20_g2 "$G2" $GRAFT_REPO_ROOT/tools/bench_sampler.py 5 4 32 20
 python3 $GRAFT_REPO_ROOT/tools/pmc_mfma.py $OUT > $OUT/summary.csv
 cat $OUT/summary.csv
+# the per-dispatch counter CSVs are ~30 MB per pass and gpurun copies back at most 64 MiB: keep the summary and the logs only
+for d in cond_g1 cond_g2 samp1_g1 samp1_g2 samp20_g1 samp20_g2; do rm -rf $OUT/$d; done
 exit $fail

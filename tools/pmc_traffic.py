@@ -37,8 +37,8 @@ for tag in sorted(acc):
                   f"-> {b / 1e6:.1f} MB per launch")
     # the dominant step launches of the shape: the two ConditionalLinear blocks (MODE 0 / 1), profiled launches only (> 10: the
     # set-up launches of other shapes in the same process are left out); the k-split fixup of the tiled kernel rides with its block
-    blocks = [v["bytes_per_launch"] for k, v in per.items() if ("k_skinny" in k or re.match(r"k_cond_gemm<", k)) and v["launches_fetch_pass"] > 10]
-    fix = [v["bytes_per_launch"] for k, v in per.items() if "k_cond_gemm_fixup" in k]
+    blocks = [v["bytes_per_launch"] for k, v in per.items() if ("k_skinny" in k or re.match(r"k_cond_gemm(_b9)?<", k)) and v["launches_fetch_pass"] > 10]
+    fix = [v["bytes_per_launch"] for k, v in per.items() if "k_cond_gemm_fixup" in k or "k_cond_gemm_b9_fixup" in k]
     if blocks:
         entries[tag] = {"step_block_bytes_per_launch": sum(blocks) / len(blocks) + (sum(fix) / len(fix) if fix else 0.0), "kernels": per}
 if jpath:
