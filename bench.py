@@ -391,11 +391,13 @@ def main():
                           if (b9 and achieved) else "fp32 TFLOP/s over the dense MFMA peak of the operand type")}
         roof["traffic"], roof["traffic_source"] = shape_traffic(args.dtype, M, K)
     roof["avg_launch_us"] = avg_us
-    roof["probe"] = {"head_interval_us": head_us, "lin2_plus_lin3_interval_us": pair_us, "record_node_us": ovh_us, "steps_probed": n_probe,
-                     "note": "HIP event-record nodes inside the timed batch graph, on the launch stream: one interval around the step head, "
-                             "ONE around the two ConditionalLinear launches, and an empty one (two record nodes back to back) that measures "
-                             "what a record node adds; avg_launch_us = (lin2_plus_lin3_interval_us - record_node_us) / 2, to be compared "
-                             "with the rocprofv3 begin->end averages of the two k_skinny / k_cond_gemm rows in profiles/"}
+    roof["probe"] = {"head_interval_us": head_us, "lin2_plus_lin3_interval_us": pair_us, "record_node_us": ovh_us, "pairs_probed": n_probe,
+                     "note": "HIP event-record NODES inside the timed batch graph, on the launch stream, around pairs of consecutive steps (i, i+1): "
+                             "one interval around head(i), ONE around the two ConditionalLinear launches of step i, one around the whole unrecorded "
+                             "step i+1; (whole step) - (two launches) = the head alone, and record_node_us = head interval - head alone is what a "
+                             "record node adds to a loaded interval; avg_launch_us = (lin2_plus_lin3_interval_us - record_node_us) / 2, to be compared "
+                             "with the rocprofv3 begin->end averages of the two k_skinny / k_cond_gemm_b9 rows in profiles/ (a profiled run clocks "
+                             "2-3 % lower)"}
     line = {
         "metric": "denoising-steps*images/sec (K=5,T=100,224^2)", "value": value, "unit": "denoising-step*images/s",
         "n_gpus": world, "n_ranks_seen": n_ranks_seen,

@@ -137,12 +137,13 @@ int nd_sample(nd_handle h, int member0, int n_members, const float *yhat_dev, co
               const float *noise_dev, float *y0_out_dev, float *seq_out_dev, int B, int mc, int T,
               int use_graph, void *stream);
 
-/* Kernel-duration probes for the roofline report: when enabled, up to 8 denoising steps of every
- * nd_sample / nd_predict_batch graph (or eager loop) get hipEvent record nodes on the launch stream: before the step head, after
- * it, after the two ConditionalLinear launches, and once more right behind (an EMPTY interval).  nd_profile_read (after the stream
- * is synchronised) returns mean intervals in microseconds over the last call's probed steps: out_us[0] step head, [1] the lin2 and
- * lin3(+lin4) launches TOGETHER, [2] 0, [3] the empty interval = what one record node adds to any interval, to be subtracted
- * when kernel time is wanted: mean step-block launch = (out_us[1] - out_us[3]) / 2.  *n_samples = probed steps.  out_us holds 4 floats. */
+/* Kernel-duration probes for the roofline report: when enabled, up to 8 PAIRS of consecutive denoising steps (i, i+1) of every
+ * nd_sample / nd_predict_batch graph (or eager loop) get hipEvent record nodes on the launch stream: before the head of step i, after
+ * it, after the two ConditionalLinear launches of step i, and after those of step i+1.  nd_profile_read (after the stream is
+ * synchronised) returns mean intervals in microseconds over the last call's probed pairs: out_us[0] head(i) + o, [1] the lin2 and
+ * lin3(+lin4) launches of step i TOGETHER + o, [2] the whole unrecorded step i+1 (head + both launches) + o, [3] o = what a record
+ * node adds to a loaded interval = out_us[0] - (out_us[2] - out_us[1]) -- the overheads cancel in [2] - [1], which is the head alone.
+ * Mean step-block launch = (out_us[1] - out_us[3]) / 2.  *n_samples = probed pairs = min(8, (T - 1) / 2).  out_us holds 4 floats. */
 int nd_set_profiling(nd_handle h, int enable);
 /* Weight bytes of one step launch (block 0: lin2 of all loaded members, 1: lin3) that are read with default-policy loads and so
  * stay resident in the 256 MiB Infinity Cache from step to step; the rest is streamed from HBM with nontemporal loads.  Lets the

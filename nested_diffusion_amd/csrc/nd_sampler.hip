@@ -31,7 +31,7 @@ extern "C" int nd_debug_set_wg_times(void* dev_ptr) {
     return hipMemcpyToSymbol(HIP_SYMBOL(nd_dbg_times), &dev_ptr, sizeof dev_ptr) == hipSuccess ? 0 : -1;
 }
 #endif
-extern "C" const char* nd_version(void) { return "libnd_hip gfx950 f32-mfma r3"; }
+extern "C" const char* nd_version(void) { return "libnd_hip gfx950 f32 (f32-input MFMA streams + bf16x9 exact-product GEMMs) r4"; }
 int nd_set_err(int code, const char* fmt, ...) {
     char buf[512];
     va_list ap;
@@ -389,7 +389,7 @@ struct nd_handle_s {
     hipStream_t capture_stream = nullptr;              // only ever used to RECORD batch graphs, never to run anything
     int encoded_B = -1;
     bool profiling = false;
-    std::vector<hipEvent_t> probe_events;   // 4 per probed step: e0 | head | e1 | lin2, lin3 | e2 | (nothing) | e3
+    std::vector<hipEvent_t> probe_events;   // 4 per probed step i: e0 | head(i) | e1 | lin2, lin3 (i) | e2 | head, lin2, lin3 (i+1) | e3
     int probe_steps = 0;
     int probe_nodes = 0;             // event-record nodes in the most recently built graph (nd_profile_probe_nodes)
 };
@@ -762,10 +762,11 @@ extern "C" int nd_profile_read(nd_handle h, float* out_us, int* n_samples) {
             HIP_CHECK(hipEventElapsedTime(&ms, h->probe_events[4 * s + k], h->probe_events[4 * s + k + 1]));
             acc[k] += ms * 1000.0;
         }
-    out_us[0] = n ? (float)(acc[0] / n) : 0.f;      // head interval
-    out_us[1] = n ? (float)(acc[1] / n) : 0.f;      // lin2 + lin3 interval (both launches, one record node)
-    out_us[2] = 0.f;
-    out_us[3] = n ? (float)(acc[2] / n) : 0.f;      // empty interval
+    out_us[0] = n ? (float)(acc[0] / n) : 0.f;      // head(i) interval              = head + o
+    out_us[1] = n ? (float)(acc[1] / n) : 0.f;      // lin2 + lin3 (i) interval      = 2 blocks + o   (both launches, one record node)
+    out_us[2] = n ? (float)(acc[2] / n) : 0.f;      // whole step i+1 interval       = head + 2 blocks + o
+    const float head = out_us[2] - out_us[1];       // the head alone: the record overheads of the two intervals cancel
+    out_us[3] = n ? (out_us[0] - head > 0.f ? out_us[0] - head : 0.f) : 0.f;     // o: what a record node adds to a loaded interval
     *n_samples = n;
     return ND_OK;
 }
@@ -913,9 +914,14 @@ static hipError_t emit_loop(nd_handle_s* h, Emitter& em, int m0, int nm, StepIO 
         for (int g = 0; g < nm; ++g) { mi.m[g].h1 = (float*)h->members[m0 + g].h1s; mi.m[g].h16 = 2; }
     }
     const dim3 tgrid((unsigned)(tp.n_full + tp.rem * tp.split)), tfix((unsigned)tp.rem * (b9 ? 8 : 4));
-    // probes: up to 8 steps spread over the loop (never step 0: its head is the cheap INIT form)
-    const int want = h->profiling ? (T - 1 < 8 ? T - 1 : 8) : 0;
+    // probes: up to 8 PAIRS of steps (i, i+1) spread over the loop (never step 0: its head is the cheap INIT form).  Records
+    // around head(i), around the two blocks of step i, and behind the blocks of step i+1: the third interval is one whole unrecorded
+    // step, so  (whole step) - (two blocks) = the head alone, and what a record node adds to an interval follows from the head's
+    // own interval -- calibrated inside the loaded graph instead of by an empty interval (two record nodes back to back cost 6 us,
+    // most of which a kernel launched behind a record node hides).
+    const int want = h->profiling ? ((T - 1) / 2 < 8 ? (T - 1) / 2 : 8) : 0;
     const int stride = want > 0 ? (T - 1) / want : 0;
+    hipEvent_t pending_end = nullptr;
     if ((int)h->probe_events.size() < 4 * want) {
         const size_t old = h->probe_events.size();
         h->probe_events.resize(4 * want);
@@ -925,8 +931,10 @@ static hipError_t emit_loop(nd_handle_s* h, Emitter& em, int m0, int nm, StepIO 
     int probed = 0;
     for (int i = 0; i < T; ++i) {
         int t = T - 1 - i, t_prev = t + 1, mode = (i == 0) ? ND_HEAD_INIT : ND_HEAD_UPDATE, istep = i;
-        const bool probe = want > 0 && i >= 1 && probed < want && ((i - 1) % stride) == stride / 2;
+        const bool probe = want > 0 && i >= 1 && i + 1 < T && !pending_end && probed < want && ((i - 1) % stride) == (stride - 1) / 2;
         hipEvent_t* ev = probe ? &h->probe_events[4 * probed] : nullptr;
+        hipEvent_t end_of_pair = pending_end;      // this step closes the pair opened by the previous one
+        pending_end = nullptr;
         if (probe) em.record(ev[0]);
         void* ah[] = {&mi, &mdev, &io, &mode, &istep, &t_prev, &t, &B, &M, &maxM, &F, &NT, &Tn};
         em.emit(head_fn(C), ghead, dim3(256), ah);
@@ -951,9 +959,9 @@ static hipError_t emit_loop(nd_handle_s* h, Emitter& em, int m0, int nm, StepIO 
             void* a3[] = {&i3, &s3, &nm, &M, &t, &cps3};
             em.emit(L3.fn, L3.grid, L3.block, a3);
         }
-        // the two ConditionalLinear launches share ONE interval (one record node for two kernels: half the distortion per launch);
-        // e2 -> e3 brackets nothing: what a record node itself adds to an interval
-        if (probe) { em.record(ev[2]); em.record(ev[3]); ++probed; }
+        // the two ConditionalLinear launches share ONE interval (one record node for two kernels: half the distortion per launch)
+        if (probe) { em.record(ev[2]); pending_end = ev[3]; ++probed; }
+        if (end_of_pair) em.record(end_of_pair);
     }
     h->probe_steps = probed;
     int eps_only = 0, par_cur = (T - 1) & 1;

@@ -311,17 +311,19 @@ __global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ x, 
     }
 }
 
-// LayerNorm -> frag32b3 for 16 rows per workgroup (4 waves x 4 rows): the pieces are gathered in LDS as the block-row's image --
+// LayerNorm -> frag32b3 for 16 rows per workgroup (16 waves, one row each): the pieces are gathered in LDS as the block-row's image --
 // which is ONE contiguous run of (dim/32) * 3 KiB in global memory -- and copied out in coalesced 16-byte units.  (The direct form
-// above scatters 8-byte pieces 256 bytes apart: 15 us per [6272, 768] launch against 8 us for the fp32 LayerNorm; this one ~9.)
+// above scatters 8-byte pieces 256 bytes apart: ~15 us per [6272, 768] launch; this one 13.5 us against 8.1 us for the fp32 LayerNorm
+// and a floor of ~10 us for 19 MB read + 29 MB written; with 4 waves x 4 rows per workgroup it took 18 us: a row is two dependent
+// shuffle reductions, four of them in a row are a latency chain.  tools/bench_ln_split.py)
 template <int VPL>
-__global__ __launch_bounds__(256) void k_layernorm_split16(const float* __restrict__ x, const float* __restrict__ gamma,
-                                                           const float* __restrict__ beta, bf16x8* __restrict__ out, int rows, int dim, float eps) {
+__global__ __launch_bounds__(1024) void k_layernorm_split16(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, bf16x8* __restrict__ out, int rows, int dim, float eps) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ln_img[];      // [dim/32][3][64][16 B]
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, r16 = threadIdx.x >> 6;
     const int nkb = dim >> 5;
-    for (int rr = 0; rr < 4; ++rr) {
-        const int r16 = wave * 4 + rr, row = blockIdx.x * 16 + r16;
+    {
+        const int row = blockIdx.x * 16 + r16;
         float4 v[VPL];
         float s = 0.f;
         const bool live = row < rows;
@@ -365,7 +367,7 @@ __global__ __launch_bounds__(256) void k_layernorm_split16(const float* __restri
                     nd_b9_split(o[e], h1, h2, h3);
                     p1[e] = h1; p2[e] = h2; p3[e] = h3;
                 }
-                unsigned char* q8 = ln_img + (size_t)(c >> 5) * 3072 + ((r16 & 15) + 16 * ((c & 31) >> 3)) * 16 + ((c & 7) >> 2) * 8;
+                unsigned char* q8 = ln_img + (size_t)(c >> 5) * 3072 + (r16 + 16 * ((c & 31) >> 3)) * 16 + ((c & 7) >> 2) * 8;
                 *reinterpret_cast<bf16x4*>(q8) = p1;
                 *reinterpret_cast<bf16x4*>(q8 + 1024) = p2;
                 *reinterpret_cast<bf16x4*>(q8 + 2048) = p3;
@@ -375,7 +377,7 @@ __global__ __launch_bounds__(256) void k_layernorm_split16(const float* __restri
     __syncthreads();
     const uint4* src = reinterpret_cast<const uint4*>(ln_img);
     uint4* dst = reinterpret_cast<uint4*>(out + (size_t)blockIdx.x * nkb * B9_BLOCK_UNITS);
-    for (int i = threadIdx.x; i < nkb * B9_BLOCK_UNITS; i += 256) dst[i] = src[i];
+    for (int i = threadIdx.x; i < nkb * B9_BLOCK_UNITS; i += 1024) dst[i] = src[i];
 }
 
 template <bool SPLIT>
@@ -395,7 +397,7 @@ static int launch_layernorm(const float* x, const float* gamma, const float* bet
 #define LN16(V)                                                                                                                      \
         {                                                                                                                            \
             HIP_CHECK(nd_allow_dynamic_lds((const void*)k_layernorm_split16<V>, 96 * 1024, &done[V - 1]));                           \
-            hipLaunchKernelGGL((k_layernorm_split16<V>), g16, block, lds, st, x, gamma, beta, img, rows, dim, eps);                  \
+            hipLaunchKernelGGL((k_layernorm_split16<V>), g16, dim3(1024), lds, st, x, gamma, beta, img, rows, dim, eps);                  \
         }
         if (vpl <= 1) LN16(1) else if (vpl <= 2) LN16(2) else if (vpl <= 3) LN16(3) else LN16(4)
 #undef LN16

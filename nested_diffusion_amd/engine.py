@@ -153,9 +153,10 @@ class EnsembleEngine:
         check(self.lib.nd_set_profiling(self.h, 1 if enable else 0), "nd_set_profiling")
 
     def profile_read(self):
-        """(head_us, pair_us, record_us, n_probed_steps) of the last sample() / predict_batch(); synchronises the stream.
-        head_us: interval around the step head; pair_us: ONE interval around the two ConditionalLinear launches (lin2, lin3+lin4);
-        record_us: the empty interval (what a record node adds to any interval).  Mean step-block launch = (pair_us - record_us) / 2."""
+        """(head_us, pair_us, record_us, n_probed_pairs) of the last sample() / predict_batch(); synchronises the stream.
+        head_us: interval around the step head (+ one record node); pair_us: ONE interval around the two ConditionalLinear launches
+        (lin2, lin3+lin4; + one record node); record_us: what a record node adds to a loaded interval, calibrated from a whole
+        unrecorded step (nd_profile_read).  Mean step-block launch = (pair_us - record_us) / 2; head alone = head_us - record_us."""
         torch.cuda.current_stream(self.device).synchronize()
         us = (C.c_float * 4)()
         n = C.c_int(0)

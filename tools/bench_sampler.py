@@ -35,6 +35,6 @@ e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / reps
 head, pair, rec, n = eng.profile_read()
 print(f"dtype={DT} K={K} T={T} B={B} mc={mc}: sampler {ms:.3f} ms = {ms*1e3/T:.1f} us/step; "
-      f"head interval {head:.1f} us, step block {(pair - rec) / 2:.1f} us per launch (empty interval {rec:.1f} us subtracted from the "
-      f"two-launch interval; {n} probes); "
+      f"head {head - rec:.1f} us, step block {(pair - rec) / 2:.1f} us per launch (record-node overhead {rec:.1f} us, calibrated in the graph, subtracted from the "
+      f"two-launch interval; {n} probed pairs of steps); "
       f"checksum {float(y.double().sum()):.9f}")
