@@ -322,29 +322,31 @@ __global__ __launch_bounds__(512) void k_cond_gemm_b9(SkinnyDesc d0, const Skinn
     cg_epilogue_g<MODE, CG9_FA, CG9_FB>(acc, d, M, t, tl.tn * CG_F + wn * CG9_FA, tl.tm * CG_F + wm * CG9_FB, tl.tn * 2 + wn, lane, 2 * TN);
 }
 
+// One wave per (remainder tile, wave sub-tile, row fragment j): the CG9_FA column fragments of a row fragment stay together (MODE 1
+// reduces over them), everything else is spread over as many short waves as possible -- the kernel is a chain of slab reads
+// (17 us per launch with one wave per sub-tile).  Slabs added in slab order: reproducible.
 template <int MODE>
 __global__ __launch_bounds__(64) void k_cond_gemm_b9_fixup(SkinnyDesc d0, const SkinnyDesc* __restrict__ table, int M, int t, int TM,
                                                            int TN, int n_full, int split, const float* __restrict__ ws) {
     constexpr int NW = CG9_WN * CG9_WM;
-    const int lane = threadIdx.x, wave = blockIdx.x % NW, ri = blockIdx.x / NW;
+    const int lane = threadIdx.x, j = blockIdx.x % CG9_FB, wave = (blockIdx.x / CG9_FB) % NW, ri = blockIdx.x / (CG9_FB * NW);
     const int wn = wave / CG9_WM, wm = wave % CG9_WM;
     const int bid = n_full + ri, per = TM * TN;
     const int member = bid / per, r2 = bid - member * per, tn = r2 / TM, tm = r2 - tn * TM;
     const SkinnyDesc d = table ? table[member] : d0;
-    const float* pt = ws + (size_t)ri * split * (CG_T * CG_T) + (size_t)wave * (CG9_FA * CG9_FB) * 256 + lane * 4;
-    f32x4 acc[CG9_FA][CG9_FB];
+    const float* pt = ws + (size_t)ri * split * (CG_T * CG_T) + (size_t)wave * (CG9_FA * CG9_FB) * 256 + j * 256 + lane * 4;
+    f32x4 acc[CG9_FA][1];
 #pragma unroll
-    for (int i = 0; i < CG9_FA; ++i)
+    for (int i = 0; i < CG9_FA; ++i) acc[i][0] = *(const __attribute__((address_space(1))) f32x4*)(pt + (i * CG9_FB) * 256);
+#pragma unroll 4
+    for (int k = 1; k < split; ++k) {
+        f32x4 v[CG9_FA];
 #pragma unroll
-        for (int j = 0; j < CG9_FB; ++j) acc[i][j] = *(const __attribute__((address_space(1))) f32x4*)(pt + (i * CG9_FB + j) * 256);
-#pragma unroll 2
-    for (int k = 1; k < split; ++k)
+        for (int i = 0; i < CG9_FA; ++i) v[i] = *(const __attribute__((address_space(1))) f32x4*)(pt + (size_t)k * (CG_T * CG_T) + (i * CG9_FB) * 256);
 #pragma unroll
-        for (int i = 0; i < CG9_FA; ++i)
-#pragma unroll
-            for (int j = 0; j < CG9_FB; ++j)
-                acc[i][j] += *(const __attribute__((address_space(1))) f32x4*)(pt + (size_t)k * (CG_T * CG_T) + (i * CG9_FB + j) * 256);
-    cg_epilogue_g<MODE, CG9_FA, CG9_FB>(acc, d, M, t, tn * CG_F + wn * CG9_FA, tm * CG_F + wm * CG9_FB, tn * 2 + wn, lane, 2 * TN);
+        for (int i = 0; i < CG9_FA; ++i) acc[i][0] += v[i];
+    }
+    cg_epilogue_g<MODE, CG9_FA, 1>(acc, d, M, t, tn * CG_F + wn * CG9_FA, tm * CG_F + wm * CG9_FB + j, tn * 2 + wn, lane, 2 * TN);
 }
 
 size_t nd_cond_gemm_b9_dynlds() { return (size_t)CG9_NS * (CG9_WN * CG9_FA + CG9_WM * CG9_FB) * 3 * 1024; }

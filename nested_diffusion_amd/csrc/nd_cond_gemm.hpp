@@ -87,7 +87,7 @@ hipError_t nd_launch_cond_gemm(int mode, const CondGemmPlan& p, SkinnyDesc d0, c
 
 // The same blocks on the bf16 matrix pipe with exact fp32 products (frag32b3 operands, csrc/nd_b9.hpp): same argument list, same
 // plan (tile list, n_full / split, workspace); launch with 512 threads and nd_cond_gemm_b9_dynlds() bytes of dynamic LDS after one
-// nd_cond_gemm_b9_prepare() per device; fixup: rem * 8 workgroups of 64.
+// nd_cond_gemm_b9_prepare() per device; fixup: rem * 16 workgroups of 64 (one wave per tile, wave sub-tile and row fragment).
 void* nd_cond_gemm_b9_kernel(int mode);
 void* nd_cond_gemm_b9_fixup_kernel(int mode);
 size_t nd_cond_gemm_b9_dynlds();

@@ -913,7 +913,7 @@ static hipError_t emit_loop(nd_handle_s* h, Emitter& em, int m0, int nm, StepIO 
         t3 = h->descs_dev + (size_t)L_LIN3S * K + m0;
         for (int g = 0; g < nm; ++g) { mi.m[g].h1 = (float*)h->members[m0 + g].h1s; mi.m[g].h16 = 2; }
     }
-    const dim3 tgrid((unsigned)(tp.n_full + tp.rem * tp.split)), tfix((unsigned)tp.rem * (b9 ? 8 : 4));
+    const dim3 tgrid((unsigned)(tp.n_full + tp.rem * tp.split)), tfix((unsigned)tp.rem * (b9 ? 16 : 4));
     // probes: up to 8 PAIRS of steps (i, i+1) spread over the loop (never step 0: its head is the cheap INIT form).  Records
     // around head(i), around the two blocks of step i, and behind the blocks of step i+1: the third interval is one whole unrecorded
     // step, so  (whole step) - (two blocks) = the head alone, and what a record node adds to an interval follows from the head's
