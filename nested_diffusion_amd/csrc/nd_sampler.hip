@@ -706,6 +706,8 @@ extern "C" int nd_member_buffer(nd_handle h, int k, int which, float* dst_dev, i
     if (!src) return nd_set_err(ND_ERR_ARG, "which=%d unknown", which);
     if (which == 0 && rows > h->cfg.max_batch) return nd_set_err(ND_ERR_ARG, "xe holds at most max_batch rows");
     const int F = h->cfg.feature_dim;
+    // above 128 rows the step blocks of an fp32 handle run on frag32b3 images of h1 / h2 (bf16 matrix pipe): those are the live copies
+    if (h->b9 && which != 0 && rows > 128) return nd_join_rows(which == 1 ? m.h1s : m.h2s, dst_dev, rows, F, stream);
     const size_t n4 = (size_t)((rows + 15) / 16) * 16 * F / 4;
     if (h->half && which != 0)   // h1/h2 are GEMM operands (fp16 in that mode); xe never is
         hipLaunchKernelGGL(k_unpack_rows_h, dim3((unsigned)((n4 / 2 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,

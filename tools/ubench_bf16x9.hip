@@ -244,7 +244,13 @@ __global__ __launch_bounds__(256) void k_stream(const f32x4* __restrict__ p, flo
 template <int FA, int FB, int WN, int WM, int NS, int SCHED>
 __global__ __launch_bounds__(64 * WN * WM) void k_gemm_b9v2(const bf16x8* __restrict__ wP, const bf16x8* __restrict__ xP, float* __restrict__ out,
                                                             int M, int N, int K, long wStride, long xStride, int TM, int TN, int n_full, int split,
-                                                            f32x4* __restrict__ part, unsigned long long* __restrict__ clk) {
+                                                            f32x4* __restrict__ part, unsigned long long* __restrict__ clk, int stagger_ticks) {
+    // EXPERIMENT: de-phase the two workgroups that share a CU (they start together and then run in lockstep, so their prologues and
+    // epilogues -- during which a workgroup issues no MFMA -- coincide): the second residency wave of the initial dispatch waits
+    if (stagger_ticks > 0 && ((blockIdx.x / 256) & 1) && blockIdx.x < 512) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)stagger_ticks) __builtin_amdgcn_s_sleep(8);
+    }
     constexpr int NW = WN * WM, NFRAG = WN * FA + WM * FB, NPC = NFRAG * 3;
     constexpr int NP = (NPC + NW - 1) / NW;                       // LDS-DMA pieces per wave per step (the last wave may have fewer)
     // (where NPC % NW != 0 the last waves re-issue the last piece: same bytes to the same place, every wave counts NP per step)
@@ -508,7 +514,7 @@ static void run_gemm(const Shape& sh, const float* dW, const float* dX, bf16x8* 
 
 template <int FA, int FB, int WN, int WM, int NS, int SCHED>
 static void run_gemm2(const Shape& sh, const float* dW, const float* dX, bf16x8* wP, bf16x8* xP, float* dOut, const std::vector<float>& hW,
-                      const std::vector<float>& hX, int ncu, bool tail_split) {
+                      const std::vector<float>& hX, int ncu, bool tail_split, int stagger_ticks = 0) {
     const int BM = WM * FB * 16, BN = WN * FA * 16, NW = WN * WM;
     const int TM = (sh.M + BM - 1) / BM, TN = (sh.N + BN - 1) / BN, tiles = sh.batch * TM * TN;
     const int Mpad = TM * BM, Npad = TN * BN;
@@ -537,7 +543,8 @@ static void run_gemm2(const Shape& sh, const float* dW, const float* dX, bf16x8*
     }
     const int nwg = n_full + rem * split;
     auto gemm = [&]() {
-        hipLaunchKernelGGL(kern, dim3(nwg), dim3(64 * NW), lds_bytes, 0, wP, xP, dOut, sh.M, sh.N, sh.K, wStride, xStride, TM, TN, n_full, split, part, dclk);
+        hipLaunchKernelGGL(kern, dim3(nwg), dim3(64 * NW), lds_bytes, 0, wP, xP, dOut, sh.M, sh.N, sh.K, wStride, xStride, TM, TN, n_full, split, part, dclk,
+                           stagger_ticks);
         if (rem) hipLaunchKernelGGL((k_b9_fixup<FA, FB, WN, WM>), dim3(rem * NW), dim3(64), 0, 0, part, dOut, sh.M, sh.N, TM, TN, n_full, split);
     };
     CK(hipMemset(dOut, 0, (size_t)sh.batch * sh.M * sh.N * 4));
@@ -605,6 +612,7 @@ static void run_gemm2(const Shape& sh, const float* dW, const float* dX, bf16x8*
     for (int b = 0; b < n_full; ++b) { cyc += (double)hc[2 * b]; ghz += (double)hc[2 * b] / (double)hc[2 * b + 1] * 0.1; }
     cyc /= n_full; ghz /= n_full;
     const double ideal = 9.0 * FA * FB * 16.0 * occ * (NW / 4);
+    if (stagger_ticks) printf("  [second residency wave delayed by %.1f us]", stagger_ticks * 0.01);
     printf("  v2 tile %3dx%-3d %d waves NS=%d sched %d  %d wg/CU  %5d tiles = %d whole + %d x %d slabs | gemm %7.1f us = %6.1f TF-eq | vs library %.0f us: %.2fx"
            " | %.0f cyc/step (ratio %.2f) %.2f GHz | err %.2e\n",
            BN, BM, NW, NS, SCHED, occ, tiles, n_full, rem, split, us_g, flop / us_g * 1e-6, sh.yard_us, sh.yard_us / us_g, cyc / nkb, cyc / nkb / ideal, ghz,
@@ -672,6 +680,9 @@ int main(int argc, char** argv) {
         CK(hipMemcpy(dW, hW.data(), hW.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dX, hX.data(), hX.size() * 4, hipMemcpyHostToDevice));
         if (argc > 2) {
             run_gemm2<4, 2, 2, 2, 2, 0>(sh, dW, dX, wP, xP, dOut, hW, hX, ncu, false);
+            if (getenv("UB_STAGGER")) {
+                for (int tk : {500, 1000, 1500, 2000}) run_gemm2<4, 2, 2, 2, 2, 0>(sh, dW, dX, wP, xP, dOut, hW, hX, ncu, false, tk);
+            }
             run_gemm2<4, 2, 2, 2, 2, 0>(sh, dW, dX, wP, xP, dOut, hW, hX, ncu, true);
             run_gemm2<4, 2, 2, 4, 2, 0>(sh, dW, dX, wP, xP, dOut, hW, hX, ncu, true);
             run_gemm2<4, 4, 2, 2, 3, 0>(sh, dW, dX, wP, xP, dOut, hW, hX, ncu, true);
