@@ -149,6 +149,35 @@ def test_c_level_conditioner_equals_operator_by_operator_launches_and_the_oracle
             assert (smaller[k].cpu() - ref[k][:3]).abs().max() < 2e-5 * max(1.0, float(ref[k].abs().max())), k
 
 
+def test_conditioner_split_mode_equals_f32_mfma_mode(monkeypatch):
+    """The two fp32 forms of the ViT's Linear layers -- exact products from three bf16 pieces per operand on the bf16 matrix pipe
+    (ND_DTYPE_F32_SPLIT: the default where every GEMM depth is a multiple of 32) and the f32-input MFMA kernels (ND_DTYPE_F32:
+    ND_GEMM_F32=mfma_f32) -- compute the same arithmetic in different summation orders: same guiding predictions to fp32 rounding,
+    both within the oracle's tolerance; and the C-level call equals the operator-by-operator launches bitwise in either mode."""
+    from nested_diffusion_amd import _lib
+    from nested_diffusion_amd.mapping import Classifier, GuidingConditioner, VisionTransformer
+    heads, depth, img = 2, 5, 32
+    vp, mlps = _vit_and_mlps(heads=heads, depth=depth, img=img, widths=(64, 32, 32))
+    x = torch.rand(6, 3, img, img, generator=torch.Generator().manual_seed(8)).cuda()
+    ref = ref_cpu.compute_guiding_prediction(vp, mlps, x.cpu(), heads, depth, full_vit=True, share_prefix=False)
+    outs = {}
+    for mode in ("b9", "mfma_f32"):
+        monkeypatch.setenv("ND_GEMM_F32", mode)
+        vit = VisionTransformer(vp, heads)
+        assert vit.split == (mode == "b9")
+        cond = GuidingConditioner(vit, [Classifier(m) for m in mlps])
+        got = cond.compute_guiding_prediction(x, include_full_vit=True)
+        assert _lib.load().nd_cond_get_config(cond._h).contents.operand_dtype == (_lib.ND_DTYPE_F32_SPLIT if mode == "b9" else _lib.ND_DTYPE_F32)
+        for a, b in zip(got, cond.compute_guiding_prediction_py(x, include_full_vit=True)):
+            assert torch.equal(a, b), mode
+        for k in range(6):
+            assert (got[k].cpu() - ref[k]).abs().max() < 2e-5 * max(1.0, float(ref[k].abs().max())), (mode, k)
+        outs[mode] = got
+    for a, b in zip(outs["b9"], outs["mfma_f32"]):
+        assert (a - b).abs().max().item() < 2e-5 * max(1.0, float(b.abs().max()))
+        assert not torch.equal(a, b)                                  # two kernels, two summation orders: not the same code path
+
+
 def test_conditioner_driven_through_ctypes_only():
     """What a C caller of include/nested_diffusion.h does, spelled out with ctypes and raw device pointers: no
     nested_diffusion_amd.mapping / ops orchestration anywhere -- pack the MLP weights, create the conditioner, hand over the
