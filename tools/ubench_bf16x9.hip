@@ -245,11 +245,23 @@ template <int FA, int FB, int WN, int WM, int NS, int SCHED>
 __global__ __launch_bounds__(64 * WN * WM) void k_gemm_b9v2(const bf16x8* __restrict__ wP, const bf16x8* __restrict__ xP, float* __restrict__ out,
                                                             int M, int N, int K, long wStride, long xStride, int TM, int TN, int n_full, int split,
                                                             f32x4* __restrict__ part, unsigned long long* __restrict__ clk, int stagger_ticks) {
+    const unsigned long long t_entry = __builtin_amdgcn_s_memrealtime();
     // EXPERIMENT: de-phase the two workgroups that share a CU (they start together and then run in lockstep, so their prologues and
     // epilogues -- during which a workgroup issues no MFMA -- coincide): the second residency wave of the initial dispatch waits
-    if (stagger_ticks > 0 && ((blockIdx.x / 256) & 1) && blockIdx.x < 512) {
-        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-        while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)stagger_ticks) __builtin_amdgcn_s_sleep(8);
+    if (stagger_ticks > 0 && blockIdx.x < 512) {
+        // every other ARRIVAL on a CU waits (per-CU arrival counters keyed by XCC_ID / SE_ID / CU_ID, never reset: parity alternates)
+        __shared__ unsigned s_order;
+        if (threadIdx.x == 0) {
+            const unsigned hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));          // HW_REG_HW_ID
+            const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 15u;    // HW_REG_XCC_ID
+            const unsigned key = xcc * 256 + ((hw >> 13) & 7) * 32 + ((hw >> 12) & 1) * 16 + ((hw >> 8) & 15);
+            s_order = atomicAdd(reinterpret_cast<unsigned*>(clk) + 2 * 65536 + key, 1u);
+        }
+        __syncthreads();
+        if (s_order & 1) {
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)stagger_ticks) __builtin_amdgcn_s_sleep(8);
+        }
     }
     constexpr int NW = WN * WM, NFRAG = WN * FA + WM * FB, NPC = NFRAG * 3;
     constexpr int NP = (NPC + NW - 1) / NW;                       // LDS-DMA pieces per wave per step (the last wave may have fewer)
@@ -381,6 +393,7 @@ __global__ __launch_bounds__(64 * WN * WM) void k_gemm_b9v2(const bf16x8* __rest
             const int n = ((tn * WN + wn) * FA + i) * 16 + 4 * (lane >> 4), m = ((tm * WM + wm) * FB + j) * 16 + (lane & 15);
             if (m < M && n + 3 < N) *reinterpret_cast<f32x4*>(o + (size_t)m * N + n) = acc[i][j];
         }
+    if (clk && tid == 0) { clk[3 * 65536 + 2 * blockIdx.x] = t_entry; clk[3 * 65536 + 2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime(); }
 }
 
 // sums the k-slabs of the remainder tiles in slab order and stores them: one wave per (remainder tile, wave sub-tile)
@@ -535,7 +548,7 @@ static void run_gemm2(const Shape& sh, const float* dW, const float* dX, bf16x8*
     const long wStride = (long)(Npad / 16) * nkb * 192, xStride = (long)(Mpad / 16) * nkb * 192;
     static unsigned long long* dclk = nullptr;
     static f32x4* part = nullptr;
-    if (!dclk) { CK(hipMalloc(&dclk, 16 * 65536)); CK(hipMalloc(&part, (size_t)256 << 20)); }
+    if (!dclk) { CK(hipMalloc(&dclk, 48 * 65536)); CK(hipMemset(dclk, 0, 48 * 65536)); CK(hipMalloc(&part, (size_t)256 << 20)); }
     for (int b = 0; b < sh.batch; ++b) {
         const long nb = (long)(Npad / 16) * nkb, mb = (long)(Mpad / 16) * nkb;
         hipLaunchKernelGGL(k_split3, dim3((unsigned)((nb * 64 + 255) / 256)), dim3(256), 0, 0, dW + (size_t)b * sh.N * sh.K, wP + b * wStride, sh.N, sh.K, Npad);
@@ -611,6 +624,21 @@ static void run_gemm2(const Shape& sh, const float* dW, const float* dX, bf16x8*
     double cyc = 0, ghz = 0;
     for (int b = 0; b < n_full; ++b) { cyc += (double)hc[2 * b]; ghz += (double)hc[2 * b] / (double)hc[2 * b + 1] * 0.1; }
     cyc /= n_full; ghz /= n_full;
+    if (getenv("UB_LIFE")) {
+        std::vector<unsigned long long> hl(2 * (size_t)n_full);
+        CK(hipMemcpy(hl.data(), dclk + 3 * 65536, 16 * (size_t)n_full, hipMemcpyDeviceToHost));
+        unsigned long long t0 = ~0ull, t1 = 0;
+        double life = 0, loop = 0;
+        for (int b = 0; b < n_full; ++b) { t0 = hl[2 * b] < t0 ? hl[2 * b] : t0; t1 = hl[2 * b + 1] > t1 ? hl[2 * b + 1] : t1; life += (double)(hl[2 * b + 1] - hl[2 * b]) * 0.01; loop += (double)hc[2 * b + 1] * 0.01; }
+        printf("      workgroup lifetimes (last launch): first entry -> last exit %.1f us; mean lifetime %.1f us of which main loop %.1f us; sum of lifetimes / %d slots = %.1f us\n",
+               (double)(t1 - t0) * 0.01, life / n_full, loop / n_full, slots, life / slots);
+        // start-time histogram: how many workgroups entered in each 10 us window
+        int hist[32] = {0};
+        for (int b = 0; b < n_full; ++b) { const int k = (int)((hl[2 * b] - t0) / 1000); hist[k < 31 ? k : 31]++; }
+        printf("      entries per 10 us window:");
+        for (int k = 0; k < 20; ++k) printf(" %d", hist[k]);
+        printf("\n");
+    }
     const double ideal = 9.0 * FA * FB * 16.0 * occ * (NW / 4);
     if (stagger_ticks) printf("  [second residency wave delayed by %.1f us]", stagger_ticks * 0.01);
     printf("  v2 tile %3dx%-3d %d waves NS=%d sched %d  %d wg/CU  %5d tiles = %d whole + %d x %d slabs | gemm %7.1f us = %6.1f TF-eq | vs library %.0f us: %.2fx"
