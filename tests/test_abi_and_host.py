@@ -65,6 +65,14 @@ def test_abi_argument_validation_without_gpu():
     assert lib.nd_packed_bytes(3, 64, 1) == 16 * 64 * 2            # fp16 image
     assert lib.nd_packed_bytes(3, 48, 1) == 0                      # fp16 needs K % 32 == 0
     assert lib.nd_packed_bytes(3, 32, 7) == 0                      # unknown dtype
+    # frag32b3 images (csrc/nd_b9.hpp) and the split-GEMM's launch plan: host-side arithmetic only
+    assert lib.nd_split_bytes(6272, 768) == 392 * 24 * 3072 and lib.nd_split_bytes(17, 64) == 2 * 2 * 3072
+    assert lib.nd_split_bytes(16, 48) == 0 and lib.nd_split_bytes(0, 32) == 0
+    assert lib.nd_gemm_split_workspace_bytes(6272, 3072, 768) > 0          # fc2: 294 tiles of 128 x 128 on 256 CUs: the remainder is cut along K
+    assert lib.nd_gemm_split_workspace_bytes(6272, 768, 2304) == 0         # qkv: K = 768 tiles are short against the fixup: left whole
+    assert lib.nd_gemm_split_workspace_bytes(64, 768, 768) == 0 and lib.nd_gemm_split_workspace_bytes(64, 48, 768) == 0
+    assert lib.nd_gemm_split(None, None, None, None, None, None, 1, 32, 1, 0, None, 0, None) != 0
+    assert lib.nd_split_rows(None, None, 16, 32, None) != 0 and lib.nd_layernorm_split(None, None, None, None, 4, 64, 1e-6, None) != 0
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

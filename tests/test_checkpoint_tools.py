@@ -178,3 +178,45 @@ def test_skeleton_unpickler_still_refuses_other_globals(tmp_path):
         with pytest.raises(pickle.UnpicklingError, match="refusing global"):
             load_pickled(str(path))
     assert not marker.exists()
+
+
+def test_skeleton_unpickler_reads_pickles_shaped_like_old_torch_writes_them(tmp_path):
+    """A module pickled by torch 1.10 (requirements.txt:59) lacks attribute tables newer torch versions add in __init__
+    (`_non_persistent_buffers_set` exists since 1.6, the `*_with_kwargs` / `_state_dict_pre_hooks` tables do not), and timm-style
+    modules may keep a functools.partial of a torch class as an attribute: neither may stop the tensors from being read."""
+    from nested_diffusion_amd.mapping import load_pickled
+    site = tmp_path / "site"
+    site.mkdir()
+    (site / "oldstyle.py").write_text(textwrap.dedent('''
+        import functools, torch, torch.nn as nn
+        class Leaf(nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.fc = nn.Linear(4, 3)
+                self.norm_layer = functools.partial(nn.LayerNorm, eps=1e-6)     # a callable kept as an attribute
+                self.register_buffer("running", torch.arange(3.0))
+        class Root(nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.blocks = nn.ModuleList([Leaf(), Leaf()])
+                self.head = nn.Linear(3, 2)
+    '''))
+    writer = textwrap.dedent(f'''
+        import sys, torch
+        sys.path.insert(0, {str(site)!r})
+        import oldstyle
+        torch.manual_seed(5)
+        m = oldstyle.Root().eval()
+        torch.save(m.state_dict(), {str(tmp_path / "state.pth")!r})
+        for mod in m.modules():                      # strip what a torch 1.10 pickle would not contain
+            for k in list(mod.__dict__):
+                if k.endswith("_with_kwargs") or k.endswith("_always_called") or k in ("_state_dict_pre_hooks", "_load_state_dict_post_hooks",
+                                                                                     "_forward_pre_hooks_with_kwargs", "_backward_pre_hooks", "_is_full_backward_hook"):
+                    del mod.__dict__[k]
+        torch.save(m, {str(tmp_path / "old.pth")!r})
+    ''')
+    subprocess.run([sys.executable, "-c", writer], check=True)
+    want = torch.load(tmp_path / "state.pth", map_location="cpu", weights_only=True)
+    got = load_pickled(str(tmp_path / "old.pth"))
+    assert list(got) == list(want) and all(torch.equal(got[k], want[k]) for k in want)
+    assert "oldstyle" not in sys.modules
