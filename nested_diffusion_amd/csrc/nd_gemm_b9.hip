@@ -15,6 +15,7 @@
 // Epilogue (kernel and fixup alike): bias, activation, residual, then fp32 row-major store and / or a frag32b3 store of the result
 // for the GEMM that consumes it (fc1 -> fc2), so that no separate pass ever splits an activation.
 #include "nd_b9.hpp"
+#include <cstdlib>
 #include "../../include/nested_diffusion.h"
 
 int nd_set_err(int code, const char* fmt, ...);
@@ -56,6 +57,9 @@ __device__ __forceinline__ void b9_epilogue(const B9Epilogue& e, f32x4 a, int m,
     if (e.out_split) nd_b9_store4(e.out_split, N >> 5, m, n0, v[0], v[1], v[2], v[3]);     // N % 32 == 0 (checked on the host)
 }
 
+// split == -1: the workgroups past n_full each take HALF of a remainder tile along its x rows (FB / 2 row fragments per wave, the whole
+// K): a last round of half-length workgroups and no partial sums -- the tail form of the two-per-CU shape, whose tiles (K = 768) are
+// short against a fixup launch.  split >= 1: k-slabs as described above.
 template <int FA, int FB, int WN, int WM, int NS>
 __global__ __launch_bounds__(64 * WN * WM) void k_gemm_b9(const bf16x8* __restrict__ xs, const bf16x8* __restrict__ ws, B9Epilogue ep, int M, int K,
                                                           int N, int n_full, int split, f32x4* __restrict__ part) {
@@ -65,6 +69,35 @@ __global__ __launch_bounds__(64 * WN * WM) void k_gemm_b9(const bf16x8* __restri
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave / WM, wm = wave % WM;
     const int TN = (N + WN * FA * 16 - 1) / (WN * FA * 16);
+    if constexpr (FB % 2 == 0) {
+        if (split < 0 && (int)blockIdx.x >= n_full) {
+            constexpr int HB = FB / 2, HPC = (WN * FA + WM * HB) * 3, HP = (HPC + NW - 1) / NW;
+            const int j = blockIdx.x - n_full, tile = n_full + (j >> 1), half = j & 1;
+            const int tm = tile / TN, tn = tile - tm * TN;
+            const int nkb = K >> 5, nfr = (N + 15) >> 4, mfr = (M + 15) >> 4;
+            const int mf0 = tm * WM * FB + half * WM * HB;              // first x fragment of this half tile
+            const bf16x8* src[HP];
+#pragma unroll
+            for (int u = 0; u < HP; ++u) {
+                const int e = min(wave * HP + u, HPC - 1), f = e / 3, pl = e % 3;
+                const bf16x8* base = f < WN * FA ? ws + (size_t)min(tn * WN * FA + f, nfr - 1) * nkb * B9_BLOCK_UNITS
+                                                 : xs + (size_t)min(mf0 + f - WN * FA, mfr - 1) * nkb * B9_BLOCK_UNITS;
+                src[u] = base + pl * 64 + lane;
+            }
+            f32x4 acc[FA][HB];
+#pragma unroll
+            for (int i = 0; i < FA; ++i)
+#pragma unroll
+                for (int jj = 0; jj < HB; ++jj) acc[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+            b9_mainloop<FA, HB, WN, WM, NS>(acc, src, lds, nkb, wave, wn, wm, lane);
+#pragma unroll
+            for (int i = 0; i < FA; ++i)
+#pragma unroll
+                for (int jj = 0; jj < HB; ++jj)
+                    b9_epilogue(ep, acc[i][jj], (mf0 + wm * HB + jj) * 16 + (lane & 15), ((tn * WN + wn) * FA + i) * 16 + 4 * (lane >> 4), M, N);
+            return;
+        }
+    }
     int bid = blockIdx.x, slab = -1, rem_index = 0;
     if (bid < n_full) {
         // blocks b and b + 8 share an XCD (round-robin dispatch): XCD x takes a contiguous run of tiles, n fastest, so the workgroups
@@ -186,21 +219,23 @@ static B9Plan nd_b9_plan(int M, int K, int N) {
     p.lds_bytes = (size_t)B9_NS * (2 * B9_FA + (p.wide ? 4 : 2) * B9_FB) * 3 * 1024;
     p.n_full = p.tiles; p.rem = 0; p.split = 1;
     const int rem = p.tiles % p.slots, nkb = K >> 5;
-    if (rem > 0 && p.tiles > p.slots) {
-        // Cost of the last round in microseconds (measured per K-step and workgroup at full residency: 1.3 us for the two-per-CU
-        // shape, 1.4 us for the wide one; ~4 us of prologue + epilogue per workgroup).  A workgroup that is alone on its CU in the
-        // two-per-CU shape has the SIMDs to itself and runs ~0.6 of the time.  A k-split adds the fixup launch: ~5 us + the slabs
-        // written and read back at ~3 TB/s.
-        const double t_step = p.wide ? 1.4 : 1.3;
-        const double lone = (!p.wide && rem <= ncu) ? 0.6 : 1.0;
-        double best = lone * (nkb * t_step + 4.0);
+    if (rem > 0 && p.tiles > p.slots && !p.wide) {
+        // two-per-CU shape (K = 768: tiles are short against a fixup launch, k-slabs + fixup cost more than they saved).  A small
+        // remainder (at most one half tile per CU) goes out as HALF tiles (split = -1: 2 * rem workgroups of half the x rows, the whole
+        // K, final results, no fixup); a larger one is left whole.  Measured on [6272, 768] x N (tools/bench_gemm_split_epilogue.py,
+        // half / whole): N = 768 (588 tiles, rem 76) 59.3 / 63.2 us, N = 2304 (rem 228) 155.9 / 151.1, N = 3072 (rem 304) 208.8 / 209.8.
+        if (2 * rem <= ncu) { p.split = -1; p.rem = rem; p.n_full = p.tiles - rem; }
+    } else if (rem > 0 && p.tiles > p.slots) {
+        // wide shape (K >= 2048): cost of the last round in microseconds (1.4 us per K-step and workgroup, ~4 us of prologue + epilogue
+        // per workgroup); a k-split adds the fixup launch: ~5 us + the slabs written and read back at ~3 TB/s
+        const double t_step = 1.4;
+        double best = nkb * t_step + 4.0;
         const int cand[] = {2, 3, 4, 6, 8};
         for (int s : cand) {
             if (nkb / s < 4) continue;
             const long slabs = (long)rem * s;
             const double rounds = (double)((slabs + p.slots - 1) / p.slots);
-            const double alone = (!p.wide && slabs <= ncu) ? 0.6 : 1.0;
-            const double t = rounds * alone * ((double)nkb / s * t_step + 5.0) + 5.0 + (double)slabs * BM * BN * 4.0 * 2.0 / 3.0e6;
+            const double t = rounds * ((double)nkb / s * t_step + 5.0) + 5.0 + (double)slabs * BM * BN * 4.0 * 2.0 / 3.0e6;
             if (t < best - 1e-9) { best = t; p.split = s; }
         }
         if (p.split > 1) { p.rem = rem; p.n_full = p.tiles - rem; }
@@ -259,12 +294,13 @@ extern "C" int nd_gemm_split(const void* x_split, const void* w_split, const flo
         return nd_set_err(ND_ERR_ARG, "tensors must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     B9Plan p = nd_b9_plan(M, K, N);
+    if (getenv("ND_B9_WHOLE_TAIL") && p.split < 0) { p.n_full = p.tiles; p.rem = 0; p.split = 1; }     // A/B switch for tools/bench_gemm_split_epilogue.py
     if (p.split > 1 && (!workspace || workspace_bytes < p.ws_bytes || ((uintptr_t)workspace & 15))) {
         // no (or too small / misaligned) workspace: every tile whole -- same results up to summation order, longer tail
         p.n_full = p.tiles; p.rem = 0; p.split = 1;
     }
     B9Epilogue ep{bias, res, out, (bf16x8*)out_split, act};
-    const unsigned grid = (unsigned)(p.n_full + p.rem * p.split);
+    const unsigned grid = (unsigned)(p.n_full + p.rem * (p.split < 0 ? 2 : p.split));
     static unsigned long long done_n = 0, done_w = 0;
     if (p.wide) {
         auto kern = k_gemm_b9<B9_FA, B9_FB, 2, 4, B9_NS>;
@@ -279,7 +315,7 @@ extern "C" int nd_gemm_split(const void* x_split, const void* w_split, const flo
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), p.lds_bytes, st, (const bf16x8*)x_split, (const bf16x8*)w_split, ep, M, K, N, p.n_full, p.split,
                            (f32x4*)workspace);
         HIP_CHECK(hipGetLastError());
-        if (p.rem > 0) hipLaunchKernelGGL((k_b9_fixup<B9_FA, B9_FB, 2, 2>), dim3(p.rem * 4 * B9_FA * B9_FB / 4), dim3(256), 0, st, (const f32x4*)workspace, ep, M, N, p.n_full, p.split);
+        if (p.rem > 0 && p.split > 1) hipLaunchKernelGGL((k_b9_fixup<B9_FA, B9_FB, 2, 2>), dim3(p.rem * 4 * B9_FA * B9_FB / 4), dim3(256), 0, st, (const f32x4*)workspace, ep, M, N, p.n_full, p.split);
     }
     HIP_CHECK(hipGetLastError());
     return ND_OK;

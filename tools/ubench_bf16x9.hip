@@ -713,6 +713,7 @@ int main(int argc, char** argv) {
             }
             run_gemm2<4, 2, 2, 2, 2, 0>(sh, dW, dX, wP, xP, dOut, hW, hX, ncu, true);
             run_gemm2<4, 2, 2, 4, 2, 0>(sh, dW, dX, wP, xP, dOut, hW, hX, ncu, true);
+            run_gemm2<4, 2, 2, 4, 3, 0>(sh, dW, dX, wP, xP, dOut, hW, hX, ncu, true);
             run_gemm2<4, 4, 2, 2, 3, 0>(sh, dW, dX, wP, xP, dOut, hW, hX, ncu, true);
             CK(hipFree(dW)); CK(hipFree(dX)); CK(hipFree(dOut)); CK(hipFree(wP)); CK(hipFree(xP));
             continue;
