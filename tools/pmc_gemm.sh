@@ -1,5 +1,6 @@
 #!/bin/bash
-# PMC passes over the fp32 ViT GEMM kernel, one shape at a time (tools/bench_gemm_vit.py with ND_GEMM_ONLY); GPU box.
+# PMC passes over the ViT GEMM kernels (k_gemm_b9 = the product path, k_gemm_nt = the f32-input MFMA form), one shape at a time
+# (tools/bench_gemm_vit.py with ND_GEMM_ONLY); GPU box.
 # Counters in their own runs, kernel-trace only.  Output: gpurun_out/pmc_gemm/summary.txt
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_gemm
 mkdir -p $OUT
@@ -19,13 +20,17 @@ for shape in ("qkv", "fc2"):
     acc = collections.defaultdict(list)
     for f in glob.glob(os.path.join(sys.argv[1], shape + "_*", "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            if "k_gemm_nt" in r["Kernel_Name"]:
-                acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
-    print(f"== k_gemm_nt<128,64>, shape {shape} (M = 6272) ==")
-    for c in sorted(acc):
-        print(f"{c:32s} n={len(acc[c]):4d} mean={sum(acc[c]) / len(acc[c]):16.1f}")
-    if acc.get("GRBM_GUI_ACTIVE") and acc.get("SQ_VALU_MFMA_BUSY_CYCLES"):
-        g = sum(acc["GRBM_GUI_ACTIVE"]) / len(acc["GRBM_GUI_ACTIVE"]); m = sum(acc["SQ_VALU_MFMA_BUSY_CYCLES"]) / len(acc["SQ_VALU_MFMA_BUSY_CYCLES"])
-        print(f"mfma_busy_frac = {m / (g / 8.0 * 256 * 4):.4f}")
+            for kern in ("k_gemm_b9", "k_gemm_nt"):
+                if kern in r["Kernel_Name"]:
+                    acc[(kern, r["Counter_Name"])].append(float(r["Counter_Value"]))
+    for kern in ("k_gemm_b9", "k_gemm_nt"):
+        print(f"== {kern}, shape {shape} (M = 6272) ==")
+        a = {c: v for (k, c), v in acc.items() if k == kern}
+        for c in sorted(a):
+            print(f"{c:32s} n={len(a[c]):4d} mean={sum(a[c]) / len(a[c]):16.1f}")
+        if a.get("GRBM_GUI_ACTIVE") and a.get("SQ_VALU_MFMA_BUSY_CYCLES"):
+            g = sum(a["GRBM_GUI_ACTIVE"]) / len(a["GRBM_GUI_ACTIVE"]); m = sum(a["SQ_VALU_MFMA_BUSY_CYCLES"]) / len(a["SQ_VALU_MFMA_BUSY_CYCLES"])
+            print(f"mfma_busy_frac = {m / (g / 8.0 * 256 * 4):.4f}")
 PY
 cat $OUT/summary.txt
+for d in $OUT/qkv_* $OUT/fc2_*; do [ -d $d ] && rm -rf $d; done     # raw counter CSVs: ~30 MB per pass
