@@ -34,10 +34,12 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 static inline size_t nd_b9_bytes(int R, int K) { return (size_t)((R + 15) / 16) * (K / 32) * B9_BLOCK_UNITS * 16; }
 
 // the three bf16 pieces of one fp32 value (exact: a == (float)h1 + (float)h2 + (float)h3 for every finite a whose pieces do not
-// underflow, i.e. |a| > 2^-110 or a == 0)
+// underflow, i.e. |a| > 2^-110 or a == 0).  An infinite a (or one that rounds to an infinite bf16) keeps h1 = +-inf and zero low
+// pieces, so that it multiplies like an infinity (inf - inf would make the low pieces NaN); a NaN stays a NaN.
 __device__ __forceinline__ void nd_b9_split(float a, __bf16& h1, __bf16& h2, __bf16& h3) {
     h1 = (__bf16)a;
-    const float r1 = a - (float)h1;
+    const float f1 = (float)h1;
+    const float r1 = __builtin_isinf(f1) ? 0.f : a - f1;
     h2 = (__bf16)r1;
     h3 = (__bf16)(r1 - (float)h2);
 }

@@ -93,9 +93,14 @@ def test_split_rows_is_exact(rows, K):
     g = torch.Generator().manual_seed(rows)
     x = torch.randn(rows, K, generator=g) * torch.exp(4 * torch.randn(rows, 1, generator=g))
     x[0, :8] = torch.tensor([0.0, 1.0, -1.0, 2.0 ** -100, 1.0 + 2.0 ** -23, 3.0e38, -7.5e-30, 1.0 / 3.0])
+    x[0, 8:11] = torch.tensor([float("inf"), float("-inf"), 3.4e38])      # infinities stay infinities (3.4e38 rounds to an infinite bf16)
     s = ops.split_rows(x.cuda())
     assert s.data.numel() == ((rows + 15) // 16) * (K // 32) * 3072
-    assert torch.equal(ops.join_rows(s).cpu(), x)
+    back = ops.join_rows(s).cpu()
+    want = x.clone(); want[0, 10] = float("inf")
+    assert torch.equal(back, want)
+    x[0, 11] = float("nan")
+    assert torch.isnan(ops.join_rows(ops.split_rows(x.cuda()))[0, 11])
 
 
 @pytest.mark.parametrize("M,K,N,act,res", [(6272, 768, 2304, None, False), (6272, 768, 768, None, True), (6272, 768, 3072, "gelu", False),
