@@ -39,7 +39,7 @@ static inline size_t nd_b9_bytes(int R, int K) { return (size_t)((R + 15) / 16) 
 __device__ __forceinline__ void nd_b9_split(float a, __bf16& h1, __bf16& h2, __bf16& h3) {
     h1 = (__bf16)a;
     const float f1 = (float)h1;
-    const float r1 = __builtin_isinf(f1) ? 0.f : a - f1;
+    const float r1 = __builtin_isinf(f1) ? 0.f : a - f1;      // (A/B on one box: the guard costs nothing measurable in the conditioner)
     h2 = (__bf16)r1;
     h3 = (__bf16)(r1 - (float)h2);
 }
