@@ -27,7 +27,7 @@ for _ in range(2):
     y = eng.sample(yhat, yhat, noise, mc=mc, T=T)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-reps = 5
+reps = int(os.environ.get("ND_BENCH_REPS", "5"))     # a long loop (e.g. 80) gives tools/power_probe_sampler.sh time to sample
 e0.record()
 for _ in range(reps):
     y = eng.sample(yhat, yhat, noise, mc=mc, T=T)
