@@ -33,10 +33,13 @@ __device__ __forceinline__ float nd_softplus(float x) {
     // log1p(u) = log(w) - ((w-1)-u)/w, w = fl(1+u)  (1-2 ulp; the correction term is ~1e-8, so an approximate reciprocal
     // is enough).  Half the instructions of log1pf(expf(x)) (whose log1pf goes through f64 here) -- this function is the
     // bulk of the step kernels' epilogue, which runs on one wave per SIMD with nothing to overlap it.
+    // The operation sequence is pinned (no contraction left to the compiler, the one FMA explicit): every kernel that evaluates it
+    // returns the same bits for the same argument.
+#pragma clang fp contract(off)
     const float u = expf(-fabsf(x));
     const float w = 1.0f + u;
     const float c = (w - 1.0f) - u;
-    const float r = fmaxf(x, 0.0f) + (logf(w) - c * __builtin_amdgcn_rcpf(w));
+    const float r = fmaxf(x, 0.0f) + __builtin_fmaf(-c, __builtin_amdgcn_rcpf(w), logf(w));
     return x > 20.0f ? x : r;
 }
 
@@ -568,7 +571,16 @@ static inline int nd_num_cus() {
     }
     return cached[dev];
 }
-static inline int nd_pick_mt(int M) { return M <= 16 ? 1 : (M <= 32 ? 2 : 4); }
+// Row fragments (16 rows each) per workgroup pass: 1, 2 or 4 -- and FIVE where that saves a whole pass over the weights: 65..80 rows
+// (the reference's default batch of 70, configs/chest_x_ray.yml:66: one pass of 80 rows instead of two of 64), 129..160, ...
+// Measured against 4 everywhere on one box (profiles/r04_rows5_ab.txt): B = 70, mc = 1: 546 k -> 794 k step*img/s (fp16 operands
+// 1.50 M -> 2.12 M); fp16 operands at 640 rows (mc = 20): 4.76 M -> 5.33 M.
+static inline int nd_pick_mt(int M) {
+    if (M <= 16) return 1;
+    if (M <= 32) return 2;
+    const int f = (M + 15) / 16;
+    return (f + 4) / 5 < (f + 3) / 4 ? 5 : 4;
+}
 static inline bool nd_use_splitk(int K) { return K >= 16384; }
 
 struct SkinnyLaunch { void* fn; dim3 grid; dim3 block; int cps; int S; };
@@ -585,7 +597,7 @@ static inline SkinnyLaunch nd_skinny_launch(int K, int N, int M, int nm, int hal
     const int mt = nd_pick_mt(M);
     const int nfr = (N + 15) / 16, nch = half ? K / 32 : K / 16;
     const int mgroups = (M + 16 * mt - 1) / (16 * mt);
-    const int nfmax = mt == 4 ? 3 : 6;             // register budget (accumulators + two stages)
+    const int nfmax = mt >= 4 ? 3 : 6;             // register budget (accumulators + two stages)
     const int ncu = nd_num_cus();
     // workgroups per member: as many as keep the grid within one workgroup per CU, but no workgroup above nfmax fragments
     int wpm = ncu / nm;
@@ -621,7 +633,9 @@ static inline SkinnyLaunch nd_skinny_launch(int K, int N, int M, int nm, int hal
 #define ND_SK(MTV, NFV, WV, UV)                                                                                     \
     (half ? (nt ? (void*)k_skinny<MTV, NFV, WV, UV, MODE, true, 1> : (void*)k_skinny<MTV, NFV, WV, UV, MODE, false, 1>) \
           : (nt ? (void*)k_skinny<MTV, NFV, WV, UV, MODE, true, 0> : (void*)k_skinny<MTV, NFV, WV, UV, MODE, false, 0>))
-    if (mt == 4) {
+    if (mt == 5) {
+        L.fn = nf == 1 ? ND_SK(5, 1, 4, 2) : (nf == 2 ? ND_SK(5, 2, 4, 2) : ND_SK(5, 3, 4, 2));
+    } else if (mt == 4) {
         L.fn = nf == 1 ? ND_SK(4, 1, 4, 2) : (nf == 2 ? ND_SK(4, 2, 4, 2) : ND_SK(4, 3, 4, 2));
     } else if (mt == 2) {
         switch (nf) {

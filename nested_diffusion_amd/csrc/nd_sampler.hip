@@ -142,6 +142,19 @@ __device__ __forceinline__ void nd_reduce_eps(const float* __restrict__ epart, i
     }
 }
 
+// One element of h1 = softplus(A1[t] * (lin1.W [y_t, yhat]) + C1[t]) * xe (latent_model.py:173-177 after the folds of SURVEY 7.3):
+// a pinned sequence of FMAs, so the two step-head kernels return the same bits.  w: the 2C entries of lin1.weight's row.
+template <int C, typename WT>
+__device__ __forceinline__ float nd_head_element(const WT& w, const float (&yv)[C], const float (&yh)[C], float a, float cc, float xe) {
+#pragma clang fp contract(off)
+    float u = 0.f;
+#pragma unroll
+    for (int q = 0; q < C; ++q) u = __builtin_fmaf(w[q], yv[q], u);
+#pragma unroll
+    for (int q = 0; q < C; ++q) u = __builtin_fmaf(w[C + q], yh[q], u);
+    return nd_softplus(__builtin_fmaf(a, u, cc)) * xe;
+}
+
 #define ND_HEAD_INIT 0    // y = noise[0] + y_T_mean                       (diffusion_utils.py:139-140)
 #define ND_HEAD_UPDATE 1  // y = posterior(y, eps(t_prev), noise[i])       (diffusion_utils.py:66-92)
 #define ND_HEAD_GIVEN 2   // y = y_in (single eps_theta evaluation)
@@ -209,20 +222,11 @@ __global__ __launch_bounds__(256) void k_step_head(MemberInline mi, const Member
         }
     }
     if (!live) return;
-    float u[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int q = 0; q < C; ++q)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) u[j] += w1[j][q] * yv[q];
-#pragma unroll
-    for (int q = 0; q < C; ++q)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) u[j] += w1[j][C + q] * yh[q];
     float4 h;
-    h.x = nd_softplus(a.x * u[0] + cc.x) * xe.x;
-    h.y = nd_softplus(a.y * u[1] + cc.y) * xe.y;
-    h.z = nd_softplus(a.z * u[2] + cc.z) * xe.z;
-    h.w = nd_softplus(a.w * u[3] + cc.w) * xe.w;
+    h.x = nd_head_element<C>(w1[0], yv, yh, a.x, cc.x, xe.x);
+    h.y = nd_head_element<C>(w1[1], yv, yh, a.y, cc.y, xe.y);
+    h.z = nd_head_element<C>(w1[2], yv, yh, a.z, cc.z, xe.z);
+    h.w = nd_head_element<C>(w1[3], yv, yh, a.w, cc.w, xe.w);
     if (mb.h16 == 2)
         nd_b9_store4(reinterpret_cast<bf16x8*>(mb.h1), F >> 5, m, n, h.x, h.y, h.z, h.w);
     else if (mb.h16)
@@ -230,6 +234,132 @@ __global__ __launch_bounds__(256) void k_step_head(MemberInline mi, const Member
             f16x4{(_Float16)h.x, (_Float16)h.y, (_Float16)h.z, (_Float16)h.w};
     else
         *(__attribute__((address_space(1))) f32x4*)(mb.h1 + nd_pk(m, n, nchF)) = f32x4{h.x, h.y, h.z, h.w};
+}
+
+// Step head of the LDS-tiled blocks (M > 128 rows, h1 a frag32b3 image): k_step_head's arithmetic -- per element, and in the eps
+// reduction tree: NT <= 64 partials are one value per lane of a 64-lane shuffle tree there, four values per lane of a 16-lane tree
+// here, paired the same way, so both kernels return the same bits -- laid out for many rows.  A workgroup takes 16 rows x 1024
+// columns: it reduces eps and updates y for its rows ONCE (k_step_head: a workgroup per row and 1024 columns), and every lane
+// computes the 8 consecutive k of one row that are its 16 bytes of an MFMA operand plane, so a wave writes whole 1 KiB planes of
+// the image (k_step_head's 8-byte pieces land 256 bytes apart).
+// Grid (ceil(F/1024), ceil(M/16), members), 256 threads; F % 32 == 0, NT <= 64.
+template <int C>
+__global__ __launch_bounds__(256) void k_step_head_rows(MemberInline mi, const MemberDev* __restrict__ members, StepIO io, int mode,
+                                                        int i_step, int t_prev, int t, int B, int M, int maxM, int F, int NT, int T) {
+    typedef const __attribute__((address_space(4))) char* nd_cbytes;
+    const MemberDev mb = nd_ldc<MemberDev>((members ? (nd_cbytes)(uintptr_t)members : (nd_cbytes)__builtin_amdgcn_kernarg_segment_ptr()) +
+                                           (size_t)blockIdx.z * sizeof(MemberDev));
+    const int z = blockIdx.z, tid = threadIdx.x, m0 = blockIdx.y * 16;
+    constexpr int C2 = 2 * C;
+    __shared__ float ys[16][C], yhs[16][C];
+    {   // thread (r = tid / 16, j = tid % 16) holds partials j, j + 16, j + 32, j + 48 of row m0 + r
+        const int r = tid >> 4, j = tid & 15, m = min(m0 + r, M - 1), b = m % B;
+        const int par_new = i_step & 1;
+        nd_gf ynew = ND_GW(mb.ybuf + ((size_t)par_new * maxM + m) * C);
+        nd_gcf yold = ND_GC(mb.ybuf + ((size_t)(par_new ^ 1) * maxM + m) * C);
+        float yv[C], yh[C], ym[C], zz[C], yo[C], eps[C];
+        float al = 0.f, s_t = 0.f, s_tm1 = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            yh[c] = ND_GC(io.yhat)[z * io.yhat_ms + (size_t)b * C + c];
+            eps[c] = 0.f; ym[c] = 0.f; zz[c] = 0.f; yo[c] = 0.f;
+        }
+        if (mode != ND_HEAD_GIVEN) {
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                ym[c] = ND_GC(io.ymean)[z * io.ymean_ms + (size_t)b * C + c];
+                zz[c] = ND_GC(io.noise)[z * io.noise_ms + ((size_t)i_step * M + m) * C + c];
+            }
+        }
+        if (mode == ND_HEAD_UPDATE) {
+            al = ND_GC(io.alphas)[t_prev]; s_t = ND_GC(io.omabs)[t_prev]; s_tm1 = ND_GC(io.omabs)[t_prev - 1];
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                yo[c] = yold[c];
+                nd_gcf row = ND_GC(mb.epart + ((size_t)m * C + c) * NT);
+                // nd_reduce_eps<256, C> at NT <= 64: lane i of wave 0 starts from 0.f + row[i] (0.f past NT); shuffle steps 32 and 16
+                // pair (i, i+32) and then (i, i+16); steps 8..1 follow below; the other three waves add 0.f each
+                float q[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int tl = j + 16 * k;
+                    const float v = row[min(tl, NT - 1)];
+                    q[k] = tl < NT ? 0.f + v : 0.f;
+                }
+                float s = (q[0] + q[2]) + (q[1] + q[3]);
+#pragma unroll
+                for (int off = 8; off > 0; off >>= 1) s += __shfl_down(s, off, 16);
+                float tot = 0.f;
+                tot += s;
+                tot += 0.f; tot += 0.f; tot += 0.f;
+                eps[c] = __shfl(tot, 0, 16);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            if (mode == ND_HEAD_INIT) yv[c] = zz[c] + ym[c];
+            else if (mode == ND_HEAD_UPDATE) yv[c] = nd_posterior(yo[c], ym[c], eps[c] + ND_GC(mb.lin4_b)[c], zz[c], al, s_t, s_tm1);
+            else yv[c] = ND_GC(io.y_in)[z * io.yin_ms + (size_t)m * C + c];
+            if (j == 0) {
+                ys[r][c] = yv[c]; yhs[r][c] = yh[c];
+                if (blockIdx.x == 0 && m0 + r < M) {
+                    ynew[c] = yv[c];
+                    if (io.seq_out && mode != ND_HEAD_GIVEN) ND_GW(io.seq_out)[z * io.seq_ms + ((size_t)i_step * M + m) * C + c] = yv[c];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // lane l of a wave: row m0 + (l & 15), the 8 columns kq = l >> 4 of each 32-column block -> its 16 bytes of the three planes
+    const int lane = tid & 63, wave = tid >> 6, r = lane & 15, kq = lane >> 4;
+    const int m = m0 + r, b = min(m, M - 1) % B, nkb = F >> 5, nchF = F >> 4;
+    float yv[C], yh[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) { yv[c] = ys[r][c]; yh[c] = yhs[r][c]; }
+    bf16x8* img = reinterpret_cast<bf16x8*>(mb.h1);
+#pragma unroll 2
+    for (int it = 0; it < 8; ++it) {
+        const int kb = blockIdx.x * 32 + wave * 8 + it;
+        if (kb >= nkb) break;
+        const int n = kb * 32 + kq * 8;
+        const float4 a0 = nd_ld16<false>(mb.A1 + (size_t)t * F + n), a1 = nd_ld16<false>(mb.A1 + (size_t)t * F + n + 4);
+        const float4 c0 = nd_ld16<false>(mb.C1 + (size_t)t * F + n), c1 = nd_ld16<false>(mb.C1 + (size_t)t * F + n + 4);
+        const float4 x0 = nd_ld16<false>(mb.xe + nd_pk(b, n, nchF)), x1 = nd_ld16<false>(mb.xe + nd_pk(b, n + 4, nchF));
+        const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+        const float cv[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+        const float xv[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+        nd_gcf wrow = ND_GC(mb.lin1_w + (size_t)n * C2);       // 8 consecutive rows = 8*C2 contiguous floats
+        float w1[8][C2];
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj)
+#pragma unroll
+            for (int q = 0; q < C2; ++q) w1[jj][q] = wrow[jj * C2 + q];
+        bf16x8 p1, p2, p3;
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            const float hv = nd_head_element<C>(w1[jj], yv, yh, av[jj], cv[jj], xv[jj]);
+            __bf16 e1, e2, e3;
+            nd_b9_split(hv, e1, e2, e3);
+            p1[jj] = e1; p2[jj] = e2; p3[jj] = e3;
+        }
+        if (m < M) {
+            __attribute__((address_space(1))) bf16x8* q = (__attribute__((address_space(1))) bf16x8*)(img + ((size_t)(m0 >> 4) * nkb + kb) * B9_BLOCK_UNITS + lane);
+            q[0] = p1; q[64] = p2; q[128] = p3;
+        }
+    }
+}
+
+static void* head_rows_fn(int C) {
+    switch (C) {
+        case 1: return (void*)k_step_head_rows<1>;
+        case 2: return (void*)k_step_head_rows<2>;
+        case 3: return (void*)k_step_head_rows<3>;
+        case 4: return (void*)k_step_head_rows<4>;
+        case 5: return (void*)k_step_head_rows<5>;
+        case 6: return (void*)k_step_head_rows<6>;
+        case 7: return (void*)k_step_head_rows<7>;
+        default: return (void*)k_step_head_rows<8>;
+    }
 }
 
 static void* head_fn(int C) {
@@ -916,6 +1046,9 @@ static hipError_t emit_loop(nd_handle_s* h, Emitter& em, int m0, int nm, StepIO 
         for (int g = 0; g < nm; ++g) { mi.m[g].h1 = (float*)h->members[m0 + g].h1s; mi.m[g].h16 = 2; }
     }
     const dim3 tgrid((unsigned)(tp.n_full + tp.rem * tp.split)), tfix((unsigned)tp.rem * (b9 ? 16 : 4));
+    // ... and the head in its many-rows form (16 rows per workgroup, whole operand planes per store; same bits)
+    const bool rows_head = b9 && NT <= 64 && !getenv("ND_HEAD_PER_ROW");
+    const dim3 ghead_rows((F + 1023) / 1024, (M + 15) / 16, nm);
     // probes: up to 8 PAIRS of steps (i, i+1) spread over the loop (never step 0: its head is the cheap INIT form).  Records
     // around head(i), around the two blocks of step i, and behind the blocks of step i+1: the third interval is one whole unrecorded
     // step, so  (whole step) - (two blocks) = the head alone, and what a record node adds to an interval follows from the head's
@@ -939,7 +1072,7 @@ static hipError_t emit_loop(nd_handle_s* h, Emitter& em, int m0, int nm, StepIO 
         pending_end = nullptr;
         if (probe) em.record(ev[0]);
         void* ah[] = {&mi, &mdev, &io, &mode, &istep, &t_prev, &t, &B, &M, &maxM, &F, &NT, &Tn};
-        em.emit(head_fn(C), ghead, dim3(256), ah);
+        em.emit(rows_head ? head_rows_fn(C) : head_fn(C), rows_head ? ghead_rows : ghead, dim3(256), ah);
         if (probe) em.record(ev[1]);
         if (tp.use_tile) {
             void* a2[] = {&d0, &t2, &M, &t, &tp.TM, &tp.TN, &tp.n_full, &tp.split, &tws};
