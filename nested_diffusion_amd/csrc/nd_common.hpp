@@ -15,6 +15,8 @@
 // operands 2.5 TB/s, packed 3.9 TB/s, packed + nontemporal W loads 4.2 TB/s (plain read: 5.4-6.0).
 #pragma once
 #include <type_traits>
+#include <mutex>
+#include <unordered_set>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -207,6 +209,8 @@ __device__ __forceinline__ T nd_ldc(const __attribute__((address_space(4))) void
 // lane l's float4 holds k = 4*(l>>4)..+3 of a chunk and element jj feeds MFMA jj (same k permutation on
 // both operands).
 // H = 1: operands are frag32h (fp16), one v_mfma_f32_16x16x32_f16 per fragment pair and 32-column chunk.
+#define ND_SKINNY_STATIC_LDS (60 * 1024)
+__host__ __device__ constexpr int nd_skinny_red_bytes(int waves, int nf, int mt) { return waves * nf * mt * 1024; }
 template <int MT, int NF, int WAVES, int U, int MODE, bool NT, int H = 0>
 __global__ __launch_bounds__(WAVES * 64) void k_skinny(SkinnyInline di, const SkinnyDesc* __restrict__ table, int nm,
                                                        int M, int t, int cps) {
@@ -383,7 +387,13 @@ __global__ __launch_bounds__(WAVES * 64) void k_skinny(SkinnyInline di, const Sk
     // ---- all fragments at once: cross-wave reduction (fixed order) + epilogue, two barriers in total ----
     // red[w] holds wave w's accumulators in MFMA D order, element ((f*MT + mt)*4 + r)*64 + l  <->  n = 4*(l>>4)+r, m = l&15.
     // The reduced, activated value replaces plane 0 in place (same thread reads the four planes and writes plane 0).
-    __shared__ __attribute__((aligned(16))) float red[WAVES][NF * MT * 256];
+    // (above 60 KiB -- five or six weight fragments against four or five row fragments -- the buffer is dynamic LDS: the launcher
+    //  passes nd_skinny_dynlds<>() bytes; the smaller shapes keep their static array and their code)
+    constexpr bool DYN = nd_skinny_red_bytes(WAVES, NF, MT) > ND_SKINNY_STATIC_LDS;
+    __shared__ __attribute__((aligned(16))) float red_static[DYN ? 1 : WAVES][DYN ? 1 : NF * MT * 256];
+    extern __shared__ __attribute__((aligned(16))) float red_dynamic[];
+    float (*const red)[NF * MT * 256] = DYN ? reinterpret_cast<float (*)[NF * MT * 256]>(red_dynamic)
+                                            : reinterpret_cast<float (*)[NF * MT * 256]>(&red_static[0][0]);
 #pragma unroll
     for (int f = 0; f < NF; ++f)
 #pragma unroll
@@ -583,7 +593,15 @@ static inline int nd_pick_mt(int M) {
 }
 static inline bool nd_use_splitk(int K) { return K >= 16384; }
 
-struct SkinnyLaunch { void* fn; dim3 grid; dim3 block; int cps; int S; };
+struct SkinnyLaunch { void* fn; dim3 grid; dim3 block; int cps; int S; unsigned lds; };   // lds: dynamic LDS bytes of the launch
+
+// a kernel that asks for more than 64 KiB of dynamic LDS has to be told so once (per translation unit: the instantiations are local)
+static inline void nd_skinny_allow_lds(void* fn, unsigned bytes) {
+    static std::mutex mu;
+    static std::unordered_set<void*> done;
+    std::lock_guard<std::mutex> g(mu);
+    if (done.insert(fn).second) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
 
 // Geometry.  Measured (tools/ubench_skinny.hip, "sx" study, 5 x 67 MB at M = 32): weight stream alone 51 us, f32 MFMAs alone
 // 40 us; together 80 us with 16 waves per CU, 66 us with 8, 57 us (min 51) with FOUR -- one wave per SIMD, each keeping two
@@ -597,7 +615,7 @@ static inline SkinnyLaunch nd_skinny_launch(int K, int N, int M, int nm, int hal
     const int mt = nd_pick_mt(M);
     const int nfr = (N + 15) / 16, nch = half ? K / 32 : K / 16;
     const int mgroups = (M + 16 * mt - 1) / (16 * mt);
-    const int nfmax = mt >= 4 ? 3 : 6;             // register budget (accumulators + two stages)
+    const int nfmax = 6;                           // register budget (accumulators + two stages); LDS: see nd_skinny_red_bytes
     const int ncu = nd_num_cus();
     // workgroups per member: as many as keep the grid within one workgroup per CU, but no workgroup above nfmax fragments
     int wpm = ncu / nm;
@@ -629,14 +647,28 @@ static inline SkinnyLaunch nd_skinny_launch(int K, int N, int M, int nm, int hal
     const int nf = (nfr + wpm - 1) / wpm;          // = base + (nfr % wpm != 0): the kernel's fragment slots
     const int gx = nm * wpm;
     const bool nt = (double)nm * N * (double)K * (half ? 2.0 : 4.0) > 160e6;
-    SkinnyLaunch L{nullptr, dim3(gx, mgroups, S), dim3(256), cps, S};
+    SkinnyLaunch L{nullptr, dim3(gx, mgroups, S), dim3(256), cps, S, 0u};
 #define ND_SK(MTV, NFV, WV, UV)                                                                                     \
     (half ? (nt ? (void*)k_skinny<MTV, NFV, WV, UV, MODE, true, 1> : (void*)k_skinny<MTV, NFV, WV, UV, MODE, false, 1>) \
           : (nt ? (void*)k_skinny<MTV, NFV, WV, UV, MODE, true, 0> : (void*)k_skinny<MTV, NFV, WV, UV, MODE, false, 0>))
     if (mt == 5) {
-        L.fn = nf == 1 ? ND_SK(5, 1, 4, 2) : (nf == 2 ? ND_SK(5, 2, 4, 2) : ND_SK(5, 3, 4, 2));
+        switch (nf) {
+            case 1: L.fn = ND_SK(5, 1, 4, 2); break;
+            case 2: L.fn = ND_SK(5, 2, 4, 2); break;
+            case 3: L.fn = ND_SK(5, 3, 4, 2); break;
+            case 4: L.fn = ND_SK(5, 4, 4, 2); break;
+            case 5: L.fn = ND_SK(5, 5, 4, 2); break;
+            default: L.fn = ND_SK(5, 6, 4, 2); break;
+        }
     } else if (mt == 4) {
-        L.fn = nf == 1 ? ND_SK(4, 1, 4, 2) : (nf == 2 ? ND_SK(4, 2, 4, 2) : ND_SK(4, 3, 4, 2));
+        switch (nf) {
+            case 1: L.fn = ND_SK(4, 1, 4, 2); break;
+            case 2: L.fn = ND_SK(4, 2, 4, 2); break;
+            case 3: L.fn = ND_SK(4, 3, 4, 2); break;
+            case 4: L.fn = ND_SK(4, 4, 4, 2); break;
+            case 5: L.fn = ND_SK(4, 5, 4, 2); break;
+            default: L.fn = ND_SK(4, 6, 4, 2); break;
+        }
     } else if (mt == 2) {
         switch (nf) {
             case 1: L.fn = ND_SK(2, 1, 4, 4); break;
@@ -657,6 +689,10 @@ static inline SkinnyLaunch nd_skinny_launch(int K, int N, int M, int nm, int hal
         }
     }
 #undef ND_SK
+    if (nd_skinny_red_bytes(4, nf, mt) > ND_SKINNY_STATIC_LDS) {
+        L.lds = (unsigned)nd_skinny_red_bytes(4, nf, mt);
+        nd_skinny_allow_lds(L.fn, L.lds);
+    }
     return L;
 }
 
@@ -672,7 +708,7 @@ static inline hipError_t nd_launch_skinny_inline(const SkinnyLaunch& L, const Sk
     for (int g = 0; g < nm && g < ND_INLINE_DESCS; ++g) di.d[g] = descs[g];
     const SkinnyDesc* table = nullptr;
     void* args[] = {&di, &table, &nm, &M, &t, &cps};
-    return hipLaunchKernel(L.fn, L.grid, L.block, args, 0, st);
+    return hipLaunchKernel(L.fn, L.grid, L.block, args, L.lds, st);
 }
 
 // d0: the descriptor of a single-member launch (table == nullptr, nm == 1), else ignored: table[0 .. nm) in device memory.
@@ -682,5 +718,5 @@ static inline hipError_t nd_launch_skinny(const SkinnyLaunch& L, SkinnyDesc d0, 
     SkinnyInline di{};
     di.d[0] = d0;
     void* args[] = {&di, &table, &nm, &M, &t, &cps};
-    return hipLaunchKernel(L.fn, L.grid, L.block, args, 0, st);
+    return hipLaunchKernel(L.fn, L.grid, L.block, args, L.lds, st);
 }

@@ -1090,9 +1090,9 @@ static hipError_t emit_loop(nd_handle_s* h, Emitter& em, int m0, int nm, StepIO 
             }
         } else {
             void* a2[] = {&i2, &s2, &nm, &M, &t, &cps2};
-            em.emit(L2.fn, L2.grid, L2.block, a2);
+            em.emit(L2.fn, L2.grid, L2.block, a2, L2.lds);
             void* a3[] = {&i3, &s3, &nm, &M, &t, &cps3};
-            em.emit(L3.fn, L3.grid, L3.block, a3);
+            em.emit(L3.fn, L3.grid, L3.block, a3, L3.lds);
         }
         // the two ConditionalLinear launches share ONE interval (one record node for two kernels: half the distortion per launch)
         if (probe) { em.record(ev[2]); pending_end = ev[3]; ++probed; }
