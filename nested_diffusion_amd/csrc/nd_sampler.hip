@@ -238,11 +238,14 @@ __global__ __launch_bounds__(256) void k_step_head(MemberInline mi, const Member
 
 // Step head of the LDS-tiled blocks (M > 128 rows, h1 a frag32b3 image): k_step_head's arithmetic -- per element, and in the eps
 // reduction tree: NT <= 64 partials are one value per lane of a 64-lane shuffle tree there, four values per lane of a 16-lane tree
-// here, paired the same way, so both kernels return the same bits -- laid out for many rows.  A workgroup takes 16 rows x 1024
-// columns: it reduces eps and updates y for its rows ONCE (k_step_head: a workgroup per row and 1024 columns), and every lane
+// here, paired the same way, so both kernels return the same bits -- laid out for many rows.  A workgroup takes 16 rows x
+// ND_HEAD_ROWS_COLS columns: it reduces eps and updates y for its rows ONCE (k_step_head: a workgroup per row and 1024 columns), and every lane
 // computes the 8 consecutive k of one row that are its 16 bytes of an MFMA operand plane, so a wave writes whole 1 KiB planes of
 // the image (k_step_head's 8-byte pieces land 256 bytes apart).
-// Grid (ceil(F/1024), ceil(M/16), members), 256 threads; F % 32 == 0, NT <= 64.
+// Grid (ceil(F/ND_HEAD_ROWS_COLS), ceil(M/16), members), 256 threads; F % 32 == 0, NT <= 64.
+#ifndef ND_HEAD_ROWS_COLS
+#define ND_HEAD_ROWS_COLS 512          // columns per workgroup (a multiple of 128: 32 per wave and pass)
+#endif
 template <int C>
 __global__ __launch_bounds__(256) void k_step_head_rows(MemberInline mi, const MemberDev* __restrict__ members, StepIO io, int mode,
                                                         int i_step, int t_prev, int t, int B, int M, int maxM, int F, int NT, int T) {
@@ -317,9 +320,9 @@ __global__ __launch_bounds__(256) void k_step_head_rows(MemberInline mi, const M
 #pragma unroll
     for (int c = 0; c < C; ++c) { yv[c] = ys[r][c]; yh[c] = yhs[r][c]; }
     bf16x8* img = reinterpret_cast<bf16x8*>(mb.h1);
-#pragma unroll 2
-    for (int it = 0; it < 8; ++it) {
-        const int kb = blockIdx.x * 32 + wave * 8 + it;
+#pragma unroll
+    for (int it = 0; it < ND_HEAD_ROWS_COLS / 128; ++it) {
+        const int kb = blockIdx.x * (ND_HEAD_ROWS_COLS / 32) + wave * (ND_HEAD_ROWS_COLS / 128) + it;
         if (kb >= nkb) break;
         const int n = kb * 32 + kq * 8;
         const float4 a0 = nd_ld16<false>(mb.A1 + (size_t)t * F + n), a1 = nd_ld16<false>(mb.A1 + (size_t)t * F + n + 4);
@@ -1048,7 +1051,7 @@ static hipError_t emit_loop(nd_handle_s* h, Emitter& em, int m0, int nm, StepIO 
     const dim3 tgrid((unsigned)(tp.n_full + tp.rem * tp.split)), tfix((unsigned)tp.rem * (b9 ? 16 : 4));
     // ... and the head in its many-rows form (16 rows per workgroup, whole operand planes per store; same bits)
     const bool rows_head = b9 && NT <= 64 && !getenv("ND_HEAD_PER_ROW");
-    const dim3 ghead_rows((F + 1023) / 1024, (M + 15) / 16, nm);
+    const dim3 ghead_rows((F + ND_HEAD_ROWS_COLS - 1) / ND_HEAD_ROWS_COLS, (M + 15) / 16, nm);
     // probes: up to 8 PAIRS of steps (i, i+1) spread over the loop (never step 0: its head is the cheap INIT form).  Records
     // around head(i), around the two blocks of step i, and behind the blocks of step i+1: the third interval is one whole unrecorded
     // step, so  (whole step) - (two blocks) = the head alone, and what a record node adds to an interval follows from the head's
