@@ -61,22 +61,28 @@ __device__ __forceinline__ void nd_b9_store4(bf16x8* img, int nkb, int r, int k,
     *(__attribute__((address_space(1))) bf16x4*)(q + 4 * 64) = p3;
 }
 
+// the NP LDS-DMA pieces of one wave and K-step; bit pc of NTMASK: piece pc is requested with the nontemporal policy
+template <int PC, int NP, unsigned NTMASK>
+__device__ __forceinline__ void b9_stage_pieces(const bf16x8* const (&src)[NP], size_t step_units, bf16x8* slot, int first, int last) {
+    if constexpr (PC < NP) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[PC] + step_units),
+                                         (__attribute__((address_space(3))) void*)&slot[min(first + PC, last) * 64], 16, 0,
+                                         ((NTMASK >> PC) & 1u) ? 2 : 0);
+        b9_stage_pieces<PC + 1, NP, NTMASK>(src, step_units, slot, first, last);
+    }
+}
+
 // One workgroup's K loop.  src[u]: this wave's NP LDS-DMA sources at K-step 0 of its range (per-lane pointers: piece base + lane),
 // advanced by B9_BLOCK_UNITS per step; piece e = min(wave*NP + u, NPC-1) of a slot = (fragment e/3, plane e%3), fragments
 // 0 .. WN*FA-1 = the tile's w fragments, the rest its x fragments.  acc[i][j] += w fragment (wn*FA + i) x x fragment (wm*FB + j):
 // lane l of acc[i][j] holds D[n = 4*(l>>4) + r][m = l&15], i.e. 4 consecutive output columns n of activation row m.
-template <int FA, int FB, int WN, int WM, int NS>
-__device__ __forceinline__ void b9_mainloop(f32x4 (&acc)[FA][FB], const bf16x8* (&src)[(((WN * FA + WM * FB) * 3) + WN * WM - 1) / (WN * WM)],
-                                            bf16x8* lds, int nk, int wave, int wn, int wm, int lane) {
+template <int FA, int FB, int WN, int WM, int NS, unsigned NTMASK = 0u>
+__device__ __forceinline__ void b9_mainloop_impl(f32x4 (&acc)[FA][FB], const bf16x8* (&src)[(((WN * FA + WM * FB) * 3) + WN * WM - 1) / (WN * WM)],
+                                                 bf16x8* lds, int nk, int wave, int wn, int wm, int lane) {
     constexpr int NW = WN * WM, NFRAG = WN * FA + WM * FB, NPC = NFRAG * 3, NP = (NPC + NW - 1) / NW;
     constexpr int NM = 9 * FA * FB, NRD = 3 * (FA + FB), NMEM = NP + NRD, RATIO = NM / NMEM > 0 ? NM / NMEM : 1;
     static_assert(NS >= 2 && NP * (NS - 1) < 64, "vmcnt is a 6-bit counter");
-#define B9_STAGE(slot, step)                                                                                                        \
-    {                                                                                                                               \
-        _Pragma("unroll") for (int pc_ = 0; pc_ < NP; ++pc_)                                                                        \
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[pc_] + (size_t)(step) * B9_BLOCK_UNITS), \
-                                             (__attribute__((address_space(3))) void*)&lds[((slot) * NPC + min(wave * NP + pc_, NPC - 1)) * 64], 16, 0, 0); \
-    }
+#define B9_STAGE(slot, step) b9_stage_pieces<0, NP, NTMASK>(src, (size_t)(step) * B9_BLOCK_UNITS, lds + (size_t)(slot) * NPC * 64, wave * NP, NPC - 1);
 #define B9_READ(set, slot)                                                                                                          \
     {                                                                                                                               \
         _Pragma("unroll") for (int p = 0; p < 3; ++p) {                                                                             \
@@ -131,4 +137,28 @@ __device__ __forceinline__ void b9_mainloop(f32x4 (&acc)[FA][FB], const bf16x8* 
 #undef B9_STAGE
 #undef B9_READ
 #undef B9_TERM
+}
+
+// NTW: the w pieces (fragments 0 .. WN*FA-1 of a slot) are requested nontemporally -- for launches whose w panels are read once while
+// their x panels are re-read by every column tile, so that the stream of w does not push x out of the Infinity Cache.  Which of a
+// wave's pieces are w pieces depends on the wave: the loop is instantiated per count of leading w pieces (wave-uniform switch).
+template <int FA, int FB, int WN, int WM, int NS, bool NTW = false>
+__device__ __forceinline__ void b9_mainloop(f32x4 (&acc)[FA][FB], const bf16x8* (&src)[(((WN * FA + WM * FB) * 3) + WN * WM - 1) / (WN * WM)],
+                                            bf16x8* lds, int nk, int wave, int wn, int wm, int lane) {
+    constexpr int NW = WN * WM, NPC = (WN * FA + WM * FB) * 3, NP = (NPC + NW - 1) / NW;
+    if constexpr (!NTW) {
+        b9_mainloop_impl<FA, FB, WN, WM, NS, 0u>(acc, src, lds, nk, wave, wn, wm, lane);
+    } else {
+        static_assert(NP <= 6, "one instantiation per count of w pieces");
+        const int nw = min(max(WN * FA * 3 - wave * NP, 0), NP);
+        switch (nw) {
+            case 0: b9_mainloop_impl<FA, FB, WN, WM, NS, 0u>(acc, src, lds, nk, wave, wn, wm, lane); break;
+            case 1: b9_mainloop_impl<FA, FB, WN, WM, NS, 1u>(acc, src, lds, nk, wave, wn, wm, lane); break;
+            case 2: b9_mainloop_impl<FA, FB, WN, WM, NS, 3u>(acc, src, lds, nk, wave, wn, wm, lane); break;
+            case 3: b9_mainloop_impl<FA, FB, WN, WM, NS, 7u>(acc, src, lds, nk, wave, wn, wm, lane); break;
+            case 4: b9_mainloop_impl<FA, FB, WN, WM, NS, 15u>(acc, src, lds, nk, wave, wn, wm, lane); break;
+            case 5: b9_mainloop_impl<FA, FB, WN, WM, NS, 31u>(acc, src, lds, nk, wave, wn, wm, lane); break;
+            default: b9_mainloop_impl<FA, FB, WN, WM, NS, 63u>(acc, src, lds, nk, wave, wn, wm, lane); break;
+        }
+    }
 }

@@ -281,6 +281,9 @@ __global__ __launch_bounds__(64) void k_cond_gemm_fixup(SkinnyDesc d0, const Ski
 #define CG9_WN 2
 #define CG9_WM 4
 #define CG9_NS 2
+#ifndef CG9_NTW
+#define CG9_NTW true           // w panels nontemporal (each is read by the TM row tiles of one XCD round, then never again)
+#endif
 template <int MODE>
 __global__ __launch_bounds__(512) void k_cond_gemm_b9(SkinnyDesc d0, const SkinnyDesc* __restrict__ table, int M, int t, int TM, int TN,
                                                       int n_full, int split, float* __restrict__ ws) {
@@ -310,7 +313,7 @@ __global__ __launch_bounds__(512) void k_cond_gemm_b9(SkinnyDesc d0, const Skinn
     for (int i = 0; i < CG9_FA; ++i)
 #pragma unroll
         for (int j = 0; j < CG9_FB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    b9_mainloop<CG9_FA, CG9_FB, CG9_WN, CG9_WM, CG9_NS>(acc, src, lds9, c1 - c0, wave, wn, wm, lane);
+    b9_mainloop<CG9_FA, CG9_FB, CG9_WN, CG9_WM, CG9_NS, CG9_NTW>(acc, src, lds9, c1 - c0, wave, wn, wm, lane);
     if (tl.slab >= 0) {     // [remainder tile][slab][wave][fragment][lane]: 8 waves x 8 fragments x 1 KiB = one 128 x 128 fp32 tile
         float* pt = ws + ((size_t)tl.rem_index * split + tl.slab) * (CG_T * CG_T) + (size_t)wave * (CG9_FA * CG9_FB) * 256 + lane * 4;
 #pragma unroll
