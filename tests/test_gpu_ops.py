@@ -341,3 +341,29 @@ def test_linear_random_shapes_cover_launch_geometry():
         ref = F.relu(s * (xr @ wr.T).float() + b)
         err = (out.cpu().double() - ref.double()).abs().max().item()
         assert err <= 2e-5 * max(1.0, ref.abs().max().item()), (it, M, K, N, half, err)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+def test_linear_four_and_five_row_fragments_with_up_to_six_weight_fragments(dtype):
+    """33..128 rows: a k_skinny workgroup keeps four or five row fragments (five where that saves a pass over the weights: 65..80
+    rows in one pass) against up to six weight fragments, its cross-wave sum in dynamic LDS (96 / 120 KiB).  Wide N so that a
+    single-member launch really gets five or six fragments per workgroup, and a split-K shape (K >= 16384); against fp64."""
+    import ctypes as C
+    from nested_diffusion_amd import _lib, ops
+    lib = _lib.load()
+    half = dtype == "f16"
+    out6 = (C.c_int * 6)()
+    assert lib.nd_skinny_plan(64, 24576, 70, 1, 1 if half else 0, 0, out6) == 0
+    assert out6[1] == 1 and out6[3] == 6            # one pass over the weights for 70 rows, six fragment slots per workgroup
+    assert lib.nd_skinny_plan(64, 24576, 64, 1, 1 if half else 0, 0, out6) == 0 and out6[1] == 1 and out6[3] == 6
+    for M in (40, 64, 70, 80, 100, 128):
+        for K, N in ((64, 24576), (16384, 1536), (96, 20000)):
+            g = torch.Generator().manual_seed(M + K)
+            x = torch.randn(M, K, generator=g)
+            w = torch.randn(N, K, generator=g) / K ** 0.5
+            b = torch.randn(N, generator=g)
+            out = ops.linear(x.cuda(), ops.PackedWeight(w.cuda(), dtype=dtype), b.cuda(), act="softplus")
+            xr, wr = (x.half().double(), w.half().double()) if half else (x.double(), w.double())
+            ref = F.softplus((xr @ wr.T).float() + b)
+            err = (out.cpu().double() - ref.double()).abs().max().item()
+            assert err <= 2e-5 * max(1.0, ref.abs().max().item()), (M, K, N, err)
