@@ -17,6 +17,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // 64 (w rows) x 32 (x rows) per wave as 4 x 2 fragments of 16 x 16, K = 32 per iteration: 9 terms x 8 = 72 MFMAs of 16 cycles
+// SLEEP > 0: s_sleep SLEEP (64 cycles each) once per iteration of 1152 MFMA cycles -- a matrix pipe that idles on purpose: if the
+// chip gives the same TFLOP/s back through a higher clock, idle cycles are free and the limit is power / current, not issue
+template <int SLEEP>
 __global__ __launch_bounds__(256) void k_16x16x32(const bf16x8* __restrict__ src, float* out, int iters) {
     extern __shared__ float dyn[];
     const int lane = threadIdx.x;
@@ -42,6 +45,7 @@ __global__ __launch_bounds__(256) void k_16x16x32(const bf16x8* __restrict__ src
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[p][i], fx[q][j], acc[i][j], 0, 0, 0);
+        if (SLEEP > 0) __builtin_amdgcn_s_sleep(SLEEP);
     }
     f32x4 s = acc[0][0];
 #pragma unroll
@@ -139,7 +143,12 @@ int main() {
     const int iters = 6000;
     for (int round = 0; round < 2; ++round)
         for (int occ = 1; occ <= 2; ++occ) {
-            run("v_mfma_f32_16x16x32_bf16", k_16x16x32, src, out, ncu, occ, iters);
+            run("v_mfma_f32_16x16x32_bf16", k_16x16x32<0>, src, out, ncu, occ, iters);
+            if (occ == 1) {
+                run("  same + s_sleep 2 / iter", k_16x16x32<2>, src, out, ncu, occ, iters);
+                run("  same + s_sleep 4 / iter", k_16x16x32<4>, src, out, ncu, occ, iters);
+                run("  same + s_sleep 8 / iter", k_16x16x32<8>, src, out, ncu, occ, iters);
+            }
             run("v_mfma_f32_32x32x16_bf16", k_32x32x16<1>, src, out, ncu, occ, iters);
             run("  same, 64x64 wave tile", k_32x32x16<2>, src, out, ncu, occ, iters / 2, 2.0);
         }
