@@ -13,7 +13,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libnd_hip.so")
-SOURCES = ["nd_sampler.hip", "nd_ops.hip", "nd_vit.hip", "nd_image.hip", "nd_cond_gemm.hip", "nd_attention.hip", "nd_gemm_f32.hip",
+SOURCES = ["nd_skinny_m0.hip", "nd_skinny_m1.hip", "nd_skinny_m2.hip", "nd_sampler.hip", "nd_ops.hip", "nd_vit.hip", "nd_image.hip", "nd_cond_gemm.hip", "nd_attention.hip", "nd_gemm_f32.hip",
            "nd_conditioner.hip", "nd_rng.hip", "nd_gemm_b9.hip"]
 # per-file flags: the large-M tile kernel keeps its accumulators in VGPRs (see nd_cond_gemm.hpp)
 EXTRA_FLAGS = {"nd_cond_gemm.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "nd_attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],

@@ -610,8 +610,20 @@ static inline void nd_skinny_allow_lds(void* fn, unsigned bytes) {
 // K = 5 members: 255 workgroups), U chunks per stage chosen to keep ~8-16 KiB per wave in flight.  Weights larger than what the 256 MiB Infinity Cache keeps
 // across consecutive steps are streamed with nontemporal loads.
 // MODE 2 (split-K): S k-slabs in grid.z so that (fragment groups) x (row groups) x S ~ 256 workgroups.
+// The k_skinny family (4 row-fragment counts x 6 weight-fragment counts x 2 load policies x 2 operand types per MODE) is instantiated
+// ONCE per MODE, each in a translation unit of its own (csrc/nd_skinny_m{0,1,2}.hip define ND_SKINNY_MODE before including this
+// header); every other translation unit gets its launch plan -- kernel pointer included -- through these three functions.
+SkinnyLaunch nd_skinny_launch_m0(int K, int N, int M, int nm, int half);
+SkinnyLaunch nd_skinny_launch_m1(int K, int N, int M, int nm, int half);
+SkinnyLaunch nd_skinny_launch_m2(int K, int N, int M, int nm, int half);
 template <int MODE>
 static inline SkinnyLaunch nd_skinny_launch(int K, int N, int M, int nm, int half = 0) {
+    return MODE == 0 ? nd_skinny_launch_m0(K, N, M, nm, half) : MODE == 1 ? nd_skinny_launch_m1(K, N, M, nm, half) : nd_skinny_launch_m2(K, N, M, nm, half);
+}
+
+#ifdef ND_SKINNY_MODE
+template <int MODE>
+static inline SkinnyLaunch nd_skinny_launch_impl(int K, int N, int M, int nm, int half) {
     const int mt = nd_pick_mt(M);
     const int nfr = (N + 15) / 16, nch = half ? K / 32 : K / 16;
     const int mgroups = (M + 16 * mt - 1) / (16 * mt);
@@ -695,6 +707,7 @@ static inline SkinnyLaunch nd_skinny_launch(int K, int N, int M, int nm, int hal
     }
     return L;
 }
+#endif  // ND_SKINNY_MODE
 
 static inline size_t nd_splitk_part_floats(int M, int K, int N, int nm = 1, int half = 0) {
     const SkinnyLaunch L = nd_skinny_launch<2>(K, N, M, nm, half);

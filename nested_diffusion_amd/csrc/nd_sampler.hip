@@ -27,8 +27,9 @@ static thread_local std::string g_err;
 extern "C" const char* nd_last_error(void) { return g_err.c_str(); }
 #ifdef ND_WG_TIMING
 // debug builds only (tools/wg_times.py): where k_skinny drops its per-workgroup clocks, 3 x 8192 x 3 int64
-extern "C" int nd_debug_set_wg_times(void* dev_ptr) {
-    return hipMemcpyToSymbol(HIP_SYMBOL(nd_dbg_times), &dev_ptr, sizeof dev_ptr) == hipSuccess ? 0 : -1;
+int nd_debug_set_wg_times_m0(void*); int nd_debug_set_wg_times_m1(void*); int nd_debug_set_wg_times_m2(void*);
+extern "C" int nd_debug_set_wg_times(void* dev_ptr) {     // the k_skinny instantiations live in csrc/nd_skinny_m{0,1,2}.hip
+    return (nd_debug_set_wg_times_m0(dev_ptr) | nd_debug_set_wg_times_m1(dev_ptr) | nd_debug_set_wg_times_m2(dev_ptr)) ? -1 : 0;
 }
 #endif
 extern "C" const char* nd_version(void) { return "libnd_hip gfx950 f32 (f32-input MFMA streams + bf16x9 exact-product GEMMs) r4"; }

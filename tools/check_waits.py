@@ -1,13 +1,18 @@
-"""Compile nd_sampler.hip to ISA and flag k_skinny main loops whose waits degraded to vmcnt(0) only (a pending flat_load
+"""Compile the k_skinny translation units to ISA and flag k_skinny main loops whose waits degraded to vmcnt(0) only (a pending flat_load
 or an uncountable load before the loop does that; the software pipeline then collapses).  CPU only.
    python tools/check_waits.py"""
 import os, re, subprocess, sys, tempfile
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(root, "nested_diffusion_amd", "csrc", "nd_sampler.hip")
-out = os.path.join(tempfile.gettempdir(), "nd_sampler_check.s")
-subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", src, "-S", "--cuda-device-only", "-o", out],
-               check=True, stderr=subprocess.DEVNULL)
-txt = open(out).read()
+# the k_skinny family is instantiated in csrc/nd_skinny_m{0,1,2}.hip (one translation unit per MODE): compiled side by side
+from concurrent.futures import ThreadPoolExecutor
+def isa(m):
+    src = os.path.join(root, "nested_diffusion_amd", "csrc", f"nd_skinny_m{m}.hip")
+    out = os.path.join(tempfile.gettempdir(), f"nd_skinny_m{m}_check.s")
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", src, "-S", "--cuda-device-only", "-o", out],
+                   check=True, stderr=subprocess.DEVNULL)
+    return open(out).read()
+with ThreadPoolExecutor(max_workers=3) as ex:
+    txt = "\n".join(ex.map(isa, (0, 1, 2)))
 bad = tot = 0
 for f in re.split(r"\n(?=_Z[\w]+:\s*;)", txt):
     name = f.split(":")[0]
