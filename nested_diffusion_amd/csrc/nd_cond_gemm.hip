@@ -281,6 +281,10 @@ __global__ __launch_bounds__(64) void k_cond_gemm_fixup(SkinnyDesc d0, const Ski
 #define CG9_WN 2
 #define CG9_WM 4
 #define CG9_NS 2
+#ifndef CG9_FIX_UNROLL
+#define CG9_FIX_UNROLL 8       // slabs requested at a time by the fixup (rocprofv3: 17 us per launch with 4, 10 us with 8; the step
+                               // in the graph takes 1250-1252 us either way: the chain was not on its critical path)
+#endif
 #ifndef CG9_NTW
 #define CG9_NTW true           // w panels nontemporal (each is read by the TM row tiles of one XCD round, then never again)
 #endif
@@ -327,7 +331,8 @@ __global__ __launch_bounds__(512) void k_cond_gemm_b9(SkinnyDesc d0, const Skinn
 
 // One wave per (remainder tile, wave sub-tile, row fragment j): the CG9_FA column fragments of a row fragment stay together (MODE 1
 // reduces over them), everything else is spread over as many short waves as possible -- the kernel is a chain of slab reads
-// (17 us per launch with one wave per sub-tile).  Slabs added in slab order: reproducible.
+// (rocprofv3: 17 us per launch with one wave per sub-tile and four slabs requested at a time, 10 us with eight).  Slabs added in
+// slab order: reproducible.
 template <int MODE>
 __global__ __launch_bounds__(64) void k_cond_gemm_b9_fixup(SkinnyDesc d0, const SkinnyDesc* __restrict__ table, int M, int t, int TM,
                                                            int TN, int n_full, int split, const float* __restrict__ ws) {
@@ -341,7 +346,7 @@ __global__ __launch_bounds__(64) void k_cond_gemm_b9_fixup(SkinnyDesc d0, const 
     f32x4 acc[CG9_FA][1];
 #pragma unroll
     for (int i = 0; i < CG9_FA; ++i) acc[i][0] = *(const __attribute__((address_space(1))) f32x4*)(pt + (i * CG9_FB) * 256);
-#pragma unroll 4
+#pragma unroll CG9_FIX_UNROLL
     for (int k = 1; k < split; ++k) {
         f32x4 v[CG9_FA];
 #pragma unroll

@@ -156,7 +156,8 @@ __global__ __launch_bounds__(256) void k_b9_fixup(const f32x4* __restrict__ part
     const int bid = n_full + ri, tm = bid / TN, tn = bid - tm * TN;
     const f32x4* p = part + (((size_t)ri * split * NW + wave) * NF + f) * 64 + lane;
     f32x4 a = *(const __attribute__((address_space(1))) f32x4*)p;
-    for (int k = 1; k < split; ++k) a += *(const __attribute__((address_space(1))) f32x4*)(p + (size_t)k * NW * NF * 64);
+#pragma unroll 8
+    for (int k = 1; k < split; ++k) a += *(const __attribute__((address_space(1))) f32x4*)(p + (size_t)k * NW * NF * 64);      // all slabs in flight at once
     b9_epilogue(ep, a, ((tm * WM + wm) * FB + j) * 16 + (lane & 15), ((tn * WN + wn) * FA + i) * 16 + 4 * (lane >> 4), M, N);
 }
 
