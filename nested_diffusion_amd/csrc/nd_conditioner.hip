@@ -289,8 +289,9 @@ int nd_guiding_prediction_first(nd_cond c, const float* images, float* logits_ou
         const nd_mlp_weights& w = c->mlps[i];
         float* logits = logits_out + (size_t)i * B * C;
         ND_TRY(nd_mlp_chain(c->tok, w.w_packed, w.bias, dims, c->m, logits, B, dt, c->lin_ws, c->lin_ws_bytes, stream));
-        if (yhat_out) ND_TRY(nd_softmax_rows(logits, yhat_out + (size_t)i * B * C, B, C, stream));     // :755-758
     }
+    // softmax of every condition's logits (:755-758): rows are independent and [n_used][B][C] is contiguous -- one launch, not n_used
+    if (yhat_out) ND_TRY(nd_softmax_rows(logits_out, yhat_out, n_used * B, C, stream));
     return ND_OK;
 }
 
