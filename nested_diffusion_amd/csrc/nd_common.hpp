@@ -16,7 +16,7 @@
 #pragma once
 #include <type_traits>
 #include <mutex>
-#include <unordered_set>
+#include <unordered_map>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -593,14 +593,25 @@ static inline int nd_pick_mt(int M) {
 }
 static inline bool nd_use_splitk(int K) { return K >= 16384; }
 
-struct SkinnyLaunch { void* fn; dim3 grid; dim3 block; int cps; int S; unsigned lds; };   // lds: dynamic LDS bytes of the launch
+// err: what preparing the launch returned (the dynamic-LDS attribute of the kernel on the current device); the launchers below hand it
+// back instead of launching, so it reaches the caller through nd_set_err like any other HIP error
+struct SkinnyLaunch { void* fn; dim3 grid; dim3 block; int cps; int S; unsigned lds; hipError_t err; };   // lds: dynamic LDS bytes of the launch
 
-// a kernel that asks for more than 64 KiB of dynamic LDS has to be told so once (per translation unit: the instantiations are local)
-static inline void nd_skinny_allow_lds(void* fn, unsigned bytes) {
+// A kernel that asks for more than 64 KiB of dynamic LDS has to be told so before its first launch (graph kernel nodes included), and
+// hipFuncSetAttribute is PER DEVICE: remembered as one bit per device and kernel (devices beyond 63: set every time).  One table for the
+// whole library (inline function: one instance across translation units); failures are returned, never cached.
+inline hipError_t nd_allow_dynamic_lds(const void* fn, size_t bytes) {
     static std::mutex mu;
-    static std::unordered_set<void*> done;
+    static std::unordered_map<const void*, unsigned long long> done;      // kernel -> devices that have the attribute
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
     std::lock_guard<std::mutex> g(mu);
-    if (done.insert(fn).second) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    unsigned long long& mask = done[fn];
+    if (dev >= 0 && dev < 64 && ((mask >> dev) & 1ull)) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess && dev >= 0 && dev < 64) mask |= 1ull << dev;
+    return e;
 }
 
 // Geometry.  Measured (tools/ubench_skinny.hip, "sx" study, 5 x 67 MB at M = 32): weight stream alone 51 us, f32 MFMAs alone
@@ -659,7 +670,7 @@ static inline SkinnyLaunch nd_skinny_launch_impl(int K, int N, int M, int nm, in
     const int nf = (nfr + wpm - 1) / wpm;          // = base + (nfr % wpm != 0): the kernel's fragment slots
     const int gx = nm * wpm;
     const bool nt = (double)nm * N * (double)K * (half ? 2.0 : 4.0) > 160e6;
-    SkinnyLaunch L{nullptr, dim3(gx, mgroups, S), dim3(256), cps, S, 0u};
+    SkinnyLaunch L{nullptr, dim3(gx, mgroups, S), dim3(256), cps, S, 0u, hipSuccess};
 #define ND_SK(MTV, NFV, WV, UV)                                                                                     \
     (half ? (nt ? (void*)k_skinny<MTV, NFV, WV, UV, MODE, true, 1> : (void*)k_skinny<MTV, NFV, WV, UV, MODE, false, 1>) \
           : (nt ? (void*)k_skinny<MTV, NFV, WV, UV, MODE, true, 0> : (void*)k_skinny<MTV, NFV, WV, UV, MODE, false, 0>))
@@ -703,7 +714,7 @@ static inline SkinnyLaunch nd_skinny_launch_impl(int K, int N, int M, int nm, in
 #undef ND_SK
     if (nd_skinny_red_bytes(4, nf, mt) > ND_SKINNY_STATIC_LDS) {
         L.lds = (unsigned)nd_skinny_red_bytes(4, nf, mt);
-        nd_skinny_allow_lds(L.fn, L.lds);
+        L.err = nd_allow_dynamic_lds(L.fn, L.lds);
     }
     return L;
 }
@@ -716,6 +727,7 @@ static inline size_t nd_splitk_part_floats(int M, int K, int N, int nm = 1, int 
 
 // descs: HOST copies of the nm members' descriptors (nm <= ND_INLINE_DESCS): passed by value
 static inline hipError_t nd_launch_skinny_inline(const SkinnyLaunch& L, const SkinnyDesc* descs, int nm, int M, int t, hipStream_t st) {
+    if (L.err != hipSuccess) return L.err;
     int cps = L.cps;
     SkinnyInline di{};
     for (int g = 0; g < nm && g < ND_INLINE_DESCS; ++g) di.d[g] = descs[g];
@@ -727,6 +739,7 @@ static inline hipError_t nd_launch_skinny_inline(const SkinnyLaunch& L, const Sk
 // d0: the descriptor of a single-member launch (table == nullptr, nm == 1), else ignored: table[0 .. nm) in device memory.
 static inline hipError_t nd_launch_skinny(const SkinnyLaunch& L, SkinnyDesc d0, const SkinnyDesc* table, int nm, int M, int t,
                                           hipStream_t st) {
+    if (L.err != hipSuccess) return L.err;
     int cps = L.cps;
     SkinnyInline di{};
     di.d[0] = d0;

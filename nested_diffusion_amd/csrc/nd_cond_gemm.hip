@@ -362,9 +362,9 @@ void* nd_cond_gemm_b9_kernel(int mode) { return mode == 1 ? (void*)k_cond_gemm_b
 void* nd_cond_gemm_b9_fixup_kernel(int mode) { return mode == 1 ? (void*)k_cond_gemm_b9_fixup<1> : (void*)k_cond_gemm_b9_fixup<0>; }
 // dynamic LDS above 64 KiB has to be allowed per kernel and device before the first launch (graph kernel nodes included)
 hipError_t nd_cond_gemm_b9_prepare() {
-    hipError_t e = hipFuncSetAttribute((const void*)k_cond_gemm_b9<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nd_cond_gemm_b9_dynlds());
+    hipError_t e = nd_allow_dynamic_lds((const void*)k_cond_gemm_b9<0>, nd_cond_gemm_b9_dynlds());
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute((const void*)k_cond_gemm_b9<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nd_cond_gemm_b9_dynlds());
+    return nd_allow_dynamic_lds((const void*)k_cond_gemm_b9<1>, nd_cond_gemm_b9_dynlds());
 }
 
 // Staging depth 3: 48 KiB of LDS and 160 VGPRs per workgroup, three workgroups resident per CU.  Measured at M = 640, K = 5

@@ -274,17 +274,6 @@ extern "C" size_t nd_gemm_split_workspace_bytes(int M, int K, int N) {
     return nd_b9_plan(M, K, N).ws_bytes;
 }
 
-// hipFuncSetAttribute is per device: remember which devices have had it (one bit each)
-static hipError_t b9_allow_lds(const void* fn, size_t bytes, unsigned long long* done_mask) {
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return e;
-    if (dev < 64 && ((*done_mask >> dev) & 1ull)) return hipSuccess;
-    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    if (e == hipSuccess && dev < 64) *done_mask |= 1ull << dev;
-    return e;
-}
-
 extern "C" int nd_gemm_split(const void* x_split, const void* w_split, const float* bias, const float* res, float* out, void* out_split,
                              int M, int K, int N, int act, void* workspace, size_t workspace_bytes, void* stream) {
     if (!x_split || !w_split || (!out && !out_split)) return nd_set_err(ND_ERR_ARG, "NULL tensor");
@@ -302,17 +291,16 @@ extern "C" int nd_gemm_split(const void* x_split, const void* w_split, const flo
     }
     B9Epilogue ep{bias, res, out, (bf16x8*)out_split, act};
     const unsigned grid = (unsigned)(p.n_full + p.rem * (p.split < 0 ? 2 : p.split));
-    static unsigned long long done_n = 0, done_w = 0;
     if (p.wide) {
         auto kern = k_gemm_b9<B9_FA, B9_FB, 2, 4, B9_NS>;
-        HIP_CHECK(b9_allow_lds((const void*)kern, p.lds_bytes, &done_w));
+        HIP_CHECK(nd_allow_dynamic_lds((const void*)kern, p.lds_bytes));
         hipLaunchKernelGGL(kern, dim3(grid), dim3(512), p.lds_bytes, st, (const bf16x8*)x_split, (const bf16x8*)w_split, ep, M, K, N, p.n_full, p.split,
                            (f32x4*)workspace);
         HIP_CHECK(hipGetLastError());
         if (p.rem > 0) hipLaunchKernelGGL((k_b9_fixup<B9_FA, B9_FB, 2, 4>), dim3(p.rem * 8 * B9_FA * B9_FB / 4), dim3(256), 0, st, (const f32x4*)workspace, ep, M, N, p.n_full, p.split);
     } else {
         auto kern = k_gemm_b9<B9_FA, B9_FB, 2, 2, B9_NS>;
-        HIP_CHECK(b9_allow_lds((const void*)kern, p.lds_bytes, &done_n));
+        HIP_CHECK(nd_allow_dynamic_lds((const void*)kern, p.lds_bytes));
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), p.lds_bytes, st, (const bf16x8*)x_split, (const bf16x8*)w_split, ep, M, K, N, p.n_full, p.split,
                            (f32x4*)workspace);
         HIP_CHECK(hipGetLastError());

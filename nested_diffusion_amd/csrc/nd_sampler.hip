@@ -470,6 +470,7 @@ struct MemberHost {
     float *w_lin1, *w_lin4, *b_lin4;                      // small row-major copies
     float *e0, *e1, *xe, *ybuf, *h1, *h2, *epart, *splitk;
     void *w_lin2s = nullptr, *w_lin3s = nullptr, *h1s = nullptr, *h2s = nullptr;   // frag32b3 images (handles with max_rows > 128, fp32)
+    bool h_split = false;        // which copies of h1 / h2 the LAST launch over this member wrote: the frag32b3 images (true) or h1 / h2 (nd_member_buffer)
 };
 
 struct GraphKey {
@@ -840,8 +841,9 @@ extern "C" int nd_member_buffer(nd_handle h, int k, int which, float* dst_dev, i
     if (!src) return nd_set_err(ND_ERR_ARG, "which=%d unknown", which);
     if (which == 0 && rows > h->cfg.max_batch) return nd_set_err(ND_ERR_ARG, "xe holds at most max_batch rows");
     const int F = h->cfg.feature_dim;
-    // above 128 rows the step blocks of an fp32 handle run on frag32b3 images of h1 / h2 (bf16 matrix pipe): those are the live copies
-    if (h->b9 && which != 0 && rows > 128) return nd_join_rows(which == 1 ? m.h1s : m.h2s, dst_dev, rows, F, stream);
+    // above 128 rows the step blocks of an fp32 handle run on frag32b3 images of h1 / h2 (bf16 matrix pipe): the live copies are
+    // whichever the LAST launch over this member wrote (MemberHost::h_split), not what `rows` would pick
+    if (which != 0 && m.h_split) return nd_join_rows(which == 1 ? m.h1s : m.h2s, dst_dev, rows, F, stream);
     const size_t n4 = (size_t)((rows + 15) / 16) * 16 * F / 4;
     if (h->half && which != 0)   // h1/h2 are GEMM operands (fp16 in that mode); xe never is
         hipLaunchKernelGGL(k_unpack_rows_h, dim3((unsigned)((n4 / 2 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
@@ -917,10 +919,22 @@ static int check_rows(nd_handle_s* h, int B, int mc, int T) {
     return ND_OK;
 }
 
+// Which operand layout emit_loop picks for the step blocks of a launch over nm members at M rows (its `b9`): the frag32b3 images on the
+// bf16 matrix pipe above 128 rows where the handle holds them and the descriptors travel by value.  Recorded per member at every entry
+// point that runs the loop (graph replays included: the choice is a function of the call's shape) so that nd_member_buffer reads the
+// copies the last launch really wrote.
+static bool loop_writes_split(const nd_handle_s* h, int M, int nm) {
+    return h->b9 && nm <= ND_INLINE_DESCS && nd_cond_gemm_plan(h->cfg.feature_dim, h->cfg.feature_dim, M, nm, h->half).use_tile;
+}
+static void note_h_layout(nd_handle_s* h, int m0, int nm, bool split) {
+    for (int k = m0; k < m0 + nm; ++k) h->members[k].h_split = split;
+}
+
 // head -> lin2 -> lin3 for one member, then `final` in the requested mode (1 eps, 2 p_sample, 3 1to0)
 static int single_eval(nd_handle_s* h, int member, StepIO io, int t, int final_mode, float* out, int B, int mc, hipStream_t st) {
     const nd_config& c = h->cfg;
     const int K = c.n_members, F = c.feature_dim, C = c.y_dim, M = B * mc;
+    note_h_layout(h, member, 1, false);           // the per-member entry points always run the frag16 / frag32h forms into h1 / h2
     {
         const MemberDev* mdev = h->members_dev + member;
         MemberInline mi{};
@@ -1036,6 +1050,8 @@ static hipError_t emit_loop(nd_handle_s* h, Emitter& em, int m0, int nm, StepIO 
     SkinnyDesc d0{};
     const dim3 ghead((F + 1023) / 1024, M, nm);
     const SkinnyLaunch L2 = nd_skinny_launch<0>(F, F, M, nm, h->half), L3 = nd_skinny_launch<1>(F, F, M, nm, h->half);
+    if (L2.err != hipSuccess) return L2.err;       // the kernel's dynamic-LDS attribute could not be set on this device
+    if (L3.err != hipSuccess) return L3.err;
     int cps2 = L2.cps, cps3 = L3.cps;
     // more than 128 rows: the LDS-tiled kernel (+ its fixup for the k-split tail) takes the place of each k_skinny node
     CondGemmPlan tp = nd_cond_gemm_plan(F, F, M, nm, h->half);
@@ -1044,6 +1060,7 @@ static hipError_t emit_loop(nd_handle_s* h, Emitter& em, int m0, int nm, StepIO 
     // writes h1 as such an image (its record travels by value, so the layout is chosen per launch; the device-table path of more
     // than ND_INLINE_DESCS members keeps the f32-input MFMA kernel)
     const bool b9 = tp.use_tile && h->b9 && inl;
+    note_h_layout(h, m0, nm, b9);
     if (b9) {
         t2 = h->descs_dev + (size_t)L_LIN2S * K + m0;
         t3 = h->descs_dev + (size_t)L_LIN3S * K + m0;
@@ -1179,6 +1196,7 @@ extern "C" int nd_sample(nd_handle h, int m0, int nm, const float* yhat_dev, con
         it = h->graphs.emplace(key, exec).first;
     }
     HIP_CHECK(hipGraphLaunch(it->second, st));
+    note_h_layout(h, m0, nm, loop_writes_split(h, M, nm));
     return ND_OK;
 }
 
@@ -1263,6 +1281,7 @@ extern "C" int nd_predict_batch(nd_handle h, nd_cond c, const float* images_dev,
         return ND_OK;
     }
     HIP_CHECK(hipGraphLaunch(it->second, st));
+    note_h_layout(h, 0, g.n_members, loop_writes_split(h, B * mc, g.n_members));
     h->encoded_B = B;
     return ND_OK;
 }

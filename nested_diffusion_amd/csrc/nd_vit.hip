@@ -14,17 +14,6 @@ int nd_set_err(int code, const char* fmt, ...);
             return nd_set_err(ND_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
     } while (0)
 
-// hipFuncSetAttribute is per device: remember which devices have had it (one bit each)
-static hipError_t nd_allow_dynamic_lds(const void* fn, size_t bytes, unsigned long long* done_mask) {
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return e;
-    if (dev < 64 && ((*done_mask >> dev) & 1ull)) return hipSuccess;
-    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    if (e == hipSuccess && dev < 64) *done_mask |= 1ull << dev;
-    return e;
-}
-
 // fp32 GEMM kernel: nd_gemm_f32.hip (its own translation unit, accumulators in VGPRs)
 hipError_t nd_launch_gemm_nt_128x64(const float* x, const float* w, const float* bias, const float* res, float* out, int M, int K, int N,
                                     int act, int n_full, int split, float* part, unsigned grid, hipStream_t st);
@@ -392,11 +381,10 @@ static int launch_layernorm(const float* x, const float* gamma, const float* bet
         // 16 rows per workgroup through an LDS image (<= 96 KiB): coalesced stores
         const dim3 g16((rows + 15) / 16);
         const size_t lds = (size_t)(dim / 32) * 3072;
-        static unsigned long long done[4] = {0, 0, 0, 0};
         bf16x8* img = reinterpret_cast<bf16x8*>(out);
 #define LN16(V)                                                                                                                      \
         {                                                                                                                            \
-            HIP_CHECK(nd_allow_dynamic_lds((const void*)k_layernorm_split16<V>, 96 * 1024, &done[V - 1]));                           \
+            HIP_CHECK(nd_allow_dynamic_lds((const void*)k_layernorm_split16<V>, 96 * 1024));                                         \
             hipLaunchKernelGGL((k_layernorm_split16<V>), g16, dim3(1024), lds, st, x, gamma, beta, img, rows, dim, eps);                  \
         }
         if (vpl <= 1) LN16(1) else if (vpl <= 2) LN16(2) else if (vpl <= 3) LN16(3) else LN16(4)
@@ -555,9 +543,8 @@ template <int NF>
 static hipError_t launch_attention_h(const float* qkv, float* out, int B, int N, int heads, hipStream_t st) {
     constexpr int NFP = (NF + 1) / 2 * 2;
     const size_t lds = ((size_t)16 * NFP * AH_KLD + (size_t)64 * (16 * NFP + 8)) * sizeof(_Float16);
-    static unsigned long long attr_done = 0;
     {
-        hipError_t e = nd_allow_dynamic_lds((const void*)k_attention_h<NF>, lds, &attr_done);
+        hipError_t e = nd_allow_dynamic_lds((const void*)k_attention_h<NF>, lds);
         if (e != hipSuccess) return e;
     }
     int qs = 1;

@@ -20,24 +20,7 @@ import torch.distributed as td
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 
-# Single-process rehearsal of an N-rank run (tests only; see emulate_rank): (rank, world, sink)
-_EMULATED = None
-
-
-def emulate_rank(rank: int = None, world: int = None, sink: dict = None) -> None:
-    """Rehearse rank `rank` of a `world`-rank job inside ONE process, with no process group: rank_world() reports (rank, world) and
-    all_gather_rows() deposits this rank's padded shard in sink[rank] and assembles whatever shards the sink holds so far (rows of
-    ranks that have not run yet are zero).  Running ranks 0 .. world-1 one after the other therefore leaves, after the last one,
-    exactly the tensor the real all-gather returns on every rank.  This exists because a GPU box admits at most 6 processes on its
-    card: BASELINE configs[3]'s real shape (8 ranks x 32 rows) cannot be rehearsed there as 8 processes sharing the device.
-    emulate_rank() with no arguments switches it off."""
-    global _EMULATED
-    _EMULATED = None if rank is None else (int(rank), int(world), sink if sink is not None else {})
-
-
 def rank_world() -> Tuple[int, int]:
-    if _EMULATED is not None:
-        return _EMULATED[0], _EMULATED[1]
     if td.is_available() and td.is_initialized():
         return td.get_rank(), td.get_world_size()
     return 0, 1
@@ -91,6 +74,16 @@ def shard_bounds(n: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + q + (1 if rank < r else 0)
 
 
+def _gather_padded(pad: torch.Tensor, world: int) -> torch.Tensor:
+    """The collective itself: every rank contributes `pad` ([widest, ...]), every rank receives [world * widest, ...] in rank order.
+    RCCL gathers device tensors directly; gloo (CPU rehearsal of the N>1 path) is staged through the host."""
+    dev = pad.device
+    stage = torch.device("cpu") if (td.get_backend() == "gloo" and pad.is_cuda) else dev
+    out = torch.empty((world * pad.shape[0],) + tuple(pad.shape[1:]), dtype=pad.dtype, device=stage)
+    td.all_gather_into_tensor(out, pad.to(stage))
+    return out.to(dev)
+
+
 def all_gather_rows(local: torch.Tensor, n_total: int, world: int = None, force_collective: bool = False) -> torch.Tensor:
     """Concatenate the ranks' row shards (dim 0) in rank order with one all_gather.  Shards may be
     ragged by one row (shard_bounds); they are padded to the widest shard for the collective.
@@ -101,22 +94,9 @@ def all_gather_rows(local: torch.Tensor, n_total: int, world: int = None, force_
         return local
     q, r = divmod(n_total, world)
     widest = q + (1 if r else 0)
-    dev = local.device
-    if _EMULATED is not None:
-        # rehearsal (emulate_rank): same padding and the same unpadding below, the collective replaced by the sink
-        sink = _EMULATED[2]
-        pad = torch.zeros((widest,) + tuple(local.shape[1:]), dtype=local.dtype, device=dev)
-        pad[: local.shape[0]] = local
-        sink[rank] = pad
-        out = torch.cat([sink[k].to(dev) if k in sink else torch.zeros_like(pad) for k in range(world)], dim=0)
-    else:
-        # RCCL gathers device tensors directly; gloo (CPU rehearsal of the N>1 path) is staged through the host
-        stage = torch.device("cpu") if (td.get_backend() == "gloo" and local.is_cuda) else dev
-        pad = torch.zeros((widest,) + tuple(local.shape[1:]), dtype=local.dtype, device=stage)
-        pad[: local.shape[0]] = local.to(stage)
-        out = torch.empty((world * widest,) + tuple(local.shape[1:]), dtype=local.dtype, device=stage)
-        td.all_gather_into_tensor(out, pad)
-        out = out.to(dev)
+    pad = torch.zeros((widest,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    out = _gather_padded(pad, world)
     if r == 0:
         return out
     pieces = []

@@ -188,8 +188,17 @@ class EnsembleEngine:
                  "per fp32 product, K members per launch)" if b9 else
                  "k_cond_gemm<{0,1}> (LDS-tiled 128x128 f32-MFMA ConditionalLinear blocks, K members per launch)") if tile else
                 "k_skinny<MT,NF,4,U,{0,1}> (weight-streaming lin2 / lin3+lin4 ConditionalLinear blocks, K members per launch)")
-        return {"kernel": "k_cond_gemm" if tile else "k_skinny", "b9": bool(b9), "name": name, "workgroups": out[1], "whole_tiles": out[2],
+        plan = {"kernel": "k_cond_gemm" if tile else "k_skinny", "b9": bool(b9), "name": name, "workgroups": out[1], "whole_tiles": out[2],
                 "remainder_tiles": out[3], "split": out[4], "partials": out[5], "TM": out[6], "TN": out[7]}
+        if not tile:
+            # the weight stream's geometry (nd_skinny_plan): NF = weight-fragment slots per workgroup (1 at K = 1 member, 5-6 at K = 5),
+            # MT = row fragments per pass (nd_pick_mt), grid = (workgroups, row passes, k-slabs)
+            o6 = (C.c_int * 6)()
+            check(self.lib.nd_skinny_plan(self.F, self.F, int(M), int(n_members), self.dtype, 1, o6), "nd_skinny_plan")
+            f = (int(M) + 15) // 16
+            mt = 1 if M <= 16 else 2 if M <= 32 else (5 if (f + 4) // 5 < (f + 3) // 4 else 4)
+            plan["stream"] = {"grid": (o6[0], o6[1], o6[2]), "NF": o6[3], "MT": mt, "chunks_per_slab": o6[4], "threads": o6[5]}
+        return plan
 
     def static_buffers(self, n_members: int, B: int, mc: int, T: int, seq: bool) -> Dict[str, torch.Tensor]:
         """Fixed-address I/O tensors so the hipGraph of a (members, B, mc, T) shape is built once."""

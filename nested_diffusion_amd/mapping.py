@@ -284,27 +284,32 @@ class _SkeletonUnpickler(pickle.Unpickler):
       * torch's own weights_only allow-list (tensor / storage / parameter rebuilders, OrderedDict, dtypes ...) resolves as usual;
       * `copyreg._reconstructor` + `builtins.object` (how protocol-2 pickles rebuild any plain object) and `functools.partial`
         (an inert constructor) are let through;
-      * a class under torch.nn.modules (Linear, LayerNorm, Conv2d, Sequential, GELU ...) resolves to itself -- it is only ever
-        instantiated by object.__new__ + a __dict__ update, no code of it runs;
-      * any global of a THIRD-PARTY or missing module (timm.*, mlp.*, models.* ...) becomes a bare nn.Module subclass of the same
-        name, WITHOUT importing anything: its instances are inert containers of `_parameters` / `_buffers` / `_modules`;
+      * a class under torch.nn.modules (Linear, LayerNorm, Conv2d, Sequential, GELU ...) and any global of a THIRD-PARTY or missing
+        module (timm.*, mlp.*, models.* ...) becomes a bare nn.Module subclass of the same name, WITHOUT importing anything: its
+        instances are inert containers of `_parameters` / `_buffers` / `_modules`, built by object.__new__ + a __dict__ update.  The
+        stock pickle machine leaves REDUCE unrestricted for every global it resolves, so the REAL torch.nn classes are not handed
+        out: a crafted file could otherwise call e.g. Linear(10**9, 10**9) (an allocation); a stub's constructor takes no arguments;
       * everything else -- a global of the standard library, of builtins, of torch or numpy that is not on the allow-list
         (os.system, builtins.eval, torch.hub.load ...) -- is refused, as the weights_only unpickler refuses it."""
     _PASS = {("copyreg", "_reconstructor"): copyreg._reconstructor, ("builtins", "object"): object,
              ("functools", "partial"): functools.partial}
     _stubs: Dict[Tuple[str, str], type] = {}
 
-    @staticmethod
-    def _allowed():
-        try:
-            from torch._weights_only_unpickler import _get_allowed_globals
-            return _get_allowed_globals()
-        except Exception:                                    # private API moved: fall back to the few globals a module pickle needs
-            import collections
-            return {"collections.OrderedDict": collections.OrderedDict, "torch._utils._rebuild_tensor_v2": torch._utils._rebuild_tensor_v2,
-                    "torch._utils._rebuild_parameter": torch._utils._rebuild_parameter, "torch.FloatStorage": torch.FloatStorage,
-                    "torch.LongStorage": torch.LongStorage, "torch.nn.parameter.Parameter": torch.nn.Parameter,
-                    "builtins.set": set, "torch.Size": torch.Size}
+    _allow_list: Optional[Dict[str, object]] = None          # built once per process, not per global
+
+    @classmethod
+    def _allowed(cls):
+        if cls._allow_list is None:
+            try:
+                from torch._weights_only_unpickler import _get_allowed_globals
+                cls._allow_list = dict(_get_allowed_globals())
+            except Exception:                                # private API moved: fall back to the few globals a module pickle needs
+                import collections
+                cls._allow_list = {"collections.OrderedDict": collections.OrderedDict, "torch._utils._rebuild_tensor_v2": torch._utils._rebuild_tensor_v2,
+                                   "torch._utils._rebuild_parameter": torch._utils._rebuild_parameter, "torch.FloatStorage": torch.FloatStorage,
+                                   "torch.LongStorage": torch.LongStorage, "torch.nn.parameter.Parameter": torch.nn.Parameter,
+                                   "builtins.set": set, "torch.Size": torch.Size}
+        return cls._allow_list
 
     def find_class(self, module, name):
         # protocol < 3 pickles (what torch.save writes) carry Python-2 names: __builtin__.set, copy_reg._reconstructor ...
@@ -319,11 +324,11 @@ class _SkeletonUnpickler(pickle.Unpickler):
         if (module, name) in self._PASS:
             return self._PASS[(module, name)]
         top = module.split(".")[0]
+        is_nn_class = False
         if module.startswith("torch.nn.modules"):
             cls = getattr(sys.modules.get(module), name, None)
-            if isinstance(cls, type) and issubclass(cls, torch.nn.Module):
-                return cls
-        if top in sys.stdlib_module_names or top in ("builtins", "torch", "numpy", "nested_diffusion_amd"):
+            is_nn_class = isinstance(cls, type) and issubclass(cls, torch.nn.Module)      # looked up to classify, never returned
+        if not is_nn_class and (top in sys.stdlib_module_names or top in ("builtins", "torch", "numpy", "nested_diffusion_amd")):
             raise pickle.UnpicklingError(f"refusing global {full}: not needed to rebuild a module tree (only tensors are read; "
                                          f"see nested_diffusion_amd.mapping._SkeletonUnpickler)")
         key = (module, name)

@@ -2,7 +2,6 @@
 Every function launches HIP kernels on torch's current stream; inputs must live on the GPU."""
 from __future__ import annotations
 
-import os
 from typing import Optional, Tuple
 
 import torch
@@ -147,17 +146,14 @@ def gemm_split(x, weight: SplitMatrix, bias: Optional[torch.Tensor] = None, act=
 
 def gemm_bias_act(x: torch.Tensor, weight, bias: Optional[torch.Tensor] = None, act=None,
                   residual: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """act(x @ weight.T + bias) + residual for large row counts (ViT token matrices).
-    fp32 `weight` (or a SplitMatrix made from one) with K % 32 == 0: exact fp32 products on the bf16 matrix pipe (gemm_split; set
-    ND_GEMM_F32=mfma_f32 for the f32-input-MFMA kernel, which also takes every K % 16 == 0).
-    A float16 `weight` selects the fp16-operand kernel (x rounded to fp16 on the fly, fp32 accumulate / out; K % 32 == 0)."""
+    """act(x @ weight.T + bias) + residual for large row counts (ViT token matrices).  The kernel follows the WEIGHT the caller holds:
+    a SplitMatrix (frag32b3 image made once with split_rows, as mapping.VisionTransformer does): exact fp32 products on the bf16
+    matrix pipe (gemm_split); a plain fp32 tensor: the f32-input-MFMA kernel (any K % 16 == 0) -- never an implicit re-split of the
+    whole weight per call; a float16 tensor: the fp16-operand kernel (x rounded to fp16 on the fly, fp32 accumulate / out; K % 32 == 0)."""
     lib = _lib.load()
     if isinstance(weight, SplitMatrix):
         return gemm_split(x, weight, bias, act, residual)
     x = _f32(x, "x")
-    if (weight.is_cuda and weight.dtype == torch.float32 and x.shape[1] % 32 == 0 and weight.dim() == 2
-            and os.environ.get("ND_GEMM_F32", "b9") != "mfma_f32"):
-        return gemm_split(x, split_rows(weight), bias, act, residual)
     if not weight.is_cuda:
         raise _lib.NdError("weight must be a GPU tensor (no CPU fallback)")
     if weight.dtype == torch.float16:

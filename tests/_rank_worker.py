@@ -20,7 +20,7 @@ def main():
     ap.add_argument("--timesteps", type=int, default=100)
     ap.add_argument("--members", type=int, default=5)
     ap.add_argument("--emulate-world", type=int, default=0,
-                    help="rehearse ranks 0..N-1 of an N-rank job one after the other in THIS process (dist.emulate_rank): a GPU box "
+                    help="rehearse ranks 0..N-1 of an N-rank job one after the other in THIS process (tests/_emulated_dist.py): a GPU box "
                          "admits at most 6 processes on its card, so 8 ranks x 32 rows cannot run there as 8 processes")
     a = ap.parse_args()
     from nested_diffusion_amd import dist as nd_dist, synthetic
@@ -56,12 +56,14 @@ def main():
         return res
 
     if a.emulate_world:
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        from _emulated_dist import emulate_rank
         sink, res = {}, None
         for r in range(a.emulate_world):
-            nd_dist.emulate_rank(r, a.emulate_world, sink)
+            emulate_rank(r, a.emulate_world, sink)
             res = one_rank()                      # after the LAST rank the sink holds every shard: res is what the real gather returns
             print(f"emulated rank {r}/{a.emulate_world}: rows {nd_dist.shard_bounds(B, r, a.emulate_world)}", flush=True)
-        nd_dist.emulate_rank()
+        emulate_rank()
         res.update(world=a.emulate_world, backend="emulated", shards=sorted(sink))
         torch.save(res, a.out)
         return

@@ -220,3 +220,24 @@ def test_skeleton_unpickler_reads_pickles_shaped_like_old_torch_writes_them(tmp_
     got = load_pickled(str(tmp_path / "old.pth"))
     assert list(got) == list(want) and all(torch.equal(got[k], want[k]) for k in want)
     assert "oldstyle" not in sys.modules
+
+
+def test_skeleton_unpickler_never_calls_a_real_torch_nn_constructor(tmp_path):
+    """The stock pickle machine leaves REDUCE unrestricted for any global find_class resolves.  A file that asks for
+    torch.nn.Linear(10**9, 10**9) (4 EB of weights: an allocation attack, no code execution) must not reach the real class: every
+    torch.nn.modules class resolves to an inert stub whose constructor takes no arguments."""
+    import pickle
+    from nested_diffusion_amd.mapping import _SkeletonUnpickler, load_pickled
+
+    class AllocatesALot:
+        def __reduce__(self):
+            return (torch.nn.Linear, (10 ** 9, 10 ** 9))
+
+    path = tmp_path / "alloc.pth"
+    torch.save({"weights": torch.zeros(2), "extra": AllocatesALot()}, path)
+    with pytest.raises((TypeError, pickle.UnpicklingError)):
+        load_pickled(str(path))
+    import io
+    stub = _SkeletonUnpickler(io.BytesIO(b"")).find_class("torch.nn.modules.linear", "Linear")
+    assert stub is not torch.nn.Linear and issubclass(stub, torch.nn.Module) and stub.__name__ == "Linear"
+    assert _SkeletonUnpickler._allowed() is _SkeletonUnpickler._allowed()          # the allow-list is built once

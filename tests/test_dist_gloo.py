@@ -65,21 +65,24 @@ def test_configs3_group_shape_world8_256_rows(tmp_path):
 
 @pytest.mark.parametrize("world,n_total", [(8, 256), (3, 10), (4, 7)])
 def test_emulated_ranks_assemble_what_the_collective_returns(world, n_total):
-    """dist.emulate_rank (the one-process rehearsal the GPU tests use for world sizes the box cannot host as processes): after the
+    """tests/_emulated_dist.py (the one-process rehearsal the GPU tests use for world sizes the box cannot host as processes): after the
     last rank's pass all_gather_rows returns exactly the concatenation of the shards -- ragged splits included -- and rank_world()
     reported each (rank, world) on the way; switched off, the process is a single rank again."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from _emulated_dist import emulate_rank
     from nested_diffusion_amd import dist as nd_dist
     full = torch.arange(n_total * 3, dtype=torch.float32).reshape(n_total, 3) + 1.0
     sink, out = {}, None
     try:
         for r in range(world):
-            nd_dist.emulate_rank(r, world, sink)
+            emulate_rank(r, world, sink)
             assert nd_dist.rank_world() == (r, world)
             lo, hi = nd_dist.shard_bounds(n_total, r, world)
             out = nd_dist.all_gather_rows(full[lo:hi].clone(), n_total)
             assert out.shape == full.shape and torch.equal(out[:hi], full[:hi]) and not out[hi:].any()
     finally:
-        nd_dist.emulate_rank()
+        emulate_rank()
     assert torch.equal(out, full) and sorted(sink) == list(range(world))
     assert nd_dist.rank_world() == (0, 1)
 

@@ -12,8 +12,8 @@ from oracle import ref_cpu
 pytestmark = pytest.mark.gpu
 
 
-def _write_run(tmp, T=6, K=5, B=4):
-    embed, heads, depth, img, patch, C = 128, 2, 5, 32, 16, 2
+def _write_run(tmp, T=6, K=5, B=4, img=32, num_workers=0):
+    embed, heads, depth, patch, C = 128, 2, 5, 16, 2
     D, H, F = 3 * img * img, 64, 64
     ck = os.path.join(tmp, "ckpt")
     os.makedirs(os.path.join(ck, "MLPs"))
@@ -30,7 +30,7 @@ def _write_run(tmp, T=6, K=5, B=4):
         path = os.path.join(tmp, f"diffu{i}_ckpt_best_eph1_acc0.9000.pth")
         torch.save({"noise_estimator": p, "optimizer": {}, "epoch": 1}, path)               # :1120-1126
         paths.append(path)
-    cfg = {"data": {"dataset": "ChestXRay", "seed": 4444, "num_classes": C, "num_workers": 0, "dataroot": "PATH"},
+    cfg = {"data": {"dataset": "ChestXRay", "seed": 4444, "num_classes": C, "num_workers": num_workers, "dataroot": "PATH"},
            "model": {"type": "simple", "data_dim": D, "feature_dim": F, "hidden_dim": H, "arch": "linear", "var_type": "fixedlarge"},
            "diffusion": {"beta_schedule": "linear", "beta_start": 0.0001, "beta_end": 0.02, "timesteps": 1000, "vis_step": 100,
                          "num_figs": 10, "include_guidance": True, "apply_aux_cls": True, "trained_aux_cls_ckpt_path": ck,
@@ -221,3 +221,127 @@ def test_literal_test_sh_command_line_from_the_shim_directory(tmp_path):
     finally:
         shutil.rmtree(os.path.join(shim_dir, "results", task), ignore_errors=True)
         os.remove(os.path.join(shim_dir, cfg_rel))
+
+
+def _write_image_tree(root):
+    """<dataroot>/testing/<class>/*: the layout torchvision's ImageFolder reads (dataset_helper/chest_x_ray_dataset.py:28-51).  Seven
+    images in two classes: 8-bit RGB and single-channel ('L') files, square, non-square, already 224 x 224 and larger; plus a file
+    that is not an image.  Returns the pixel arrays by file name."""
+    import numpy as np
+    from PIL import Image
+    rng = np.random.default_rng(11)
+    px = {}
+    spec = {"NORMAL": [("a_same.png", (224, 224, 3)), ("b_gray.png", (224, 224)), ("c_big.png", (448, 448, 3)), ("d_wide.png", (180, 300, 3))],
+            "PNEUMONIA": [("e_tall.png", (301, 199, 3)), ("f_gray_small.png", (97, 131)), ("g_last.jpg", (240, 240, 3))]}
+    for cls, files in spec.items():
+        d = os.path.join(root, "testing", cls)
+        os.makedirs(d)
+        for name, shape in files:
+            arr = rng.integers(0, 256, size=shape, dtype=np.uint8)
+            Image.fromarray(arr, "RGB" if len(shape) == 3 else "L").save(os.path.join(d, name))
+            px[name] = arr
+    open(os.path.join(root, "testing", "NORMAL", "notes.txt"), "w").write("not an image")
+    return px
+
+
+def test_main_test_path_from_image_files_on_disk(tmp_path, capsys, monkeypatch):
+    """SURVEY 8(f)-4 end to end on the GPU: PNG / JPEG files on disk -> ImageFolder ordering + Grayscale(3) / Resize(224) / ToTensor
+    (dataset_helper/chest_x_ray_dataset.py:28-51) -> DataLoader(batch_size from the YAML, shuffle=False, drop_last=True)
+    (classification_train_separately.py:674-681) -> the batch loop of test_atk (:715-722) -> shard_of_batch -> nd_predict_batch ->
+    nd_report -- with NO --synthetic_batches.  7 images, batch 3: two batches, the 7th image dropped.  Checked: (i) through the literal
+    entry point scripts/diffusion/main.py in a fresh interpreter with --dataroot (main.py:184-185) and two loader worker processes:
+    rc 0, the report lines, no traceback; (ii) in-process with the batch loop observed: number of batches and images consumed, targets
+    in ImageFolder order, and the FIRST batch's tensor against the transforms written out by hand (ITU-R 601-2 luma in PIL's 16-bit
+    fixed point; identity resize at 224 x 224; (1,3,3,1)/8 taps per axis for the 448 -> 224 reduction)."""
+    import subprocess
+    import sys
+    import numpy as np
+    from nested_diffusion_amd import main as nd_main
+    import nested_diffusion_amd.runner as runner_mod
+    T, K, B = 6, 5, 3
+    ypath, *_ = _write_run(str(tmp_path), T=T, K=K, B=B, img=224)
+    cfg2 = yaml.safe_load(open(ypath))
+    cfg2["data"]["num_workers"] = 2                                   # the fresh-interpreter run decodes in loader worker processes
+    ypath_workers = os.path.join(str(tmp_path), "chest_x_ray_workers.yml")
+    yaml.safe_dump(cfg2, open(ypath_workers, "w"))
+    dataroot = os.path.join(str(tmp_path), "data")
+    px = _write_image_tree(dataroot)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    flags = ["--test", "--device", "0", "--thread", "8", "--loss", "card_onehot_conditional", "--doc", "chest_x_ray",
+             "--n_splits", "1", "--noise_perturbation", "0", "--low_resolution", "0", "--brightness", "0", "--contrast", "1", "--crop", "0",
+             "--attack_name", "None", "--eps", "0", "--ni", "--preprocess", "grayscaled", "--timesteps", str(T), "--seed", "7",
+             "--mc_trials", "2", "--dataroot", dataroot]
+    # (i) the reference's file name, a fresh interpreter, loader workers as in the reference (num_workers > 0, :675-681)
+    exp1 = os.path.join(str(tmp_path), "results_cli")
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "diffusion", "main.py")] + flags + ["--config", ypath_workers, "--exp", exp1],
+                       cwd=os.path.join(root, "scripts", "diffusion"), capture_output=True, text=True, timeout=420)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    txt = open(os.path.join(exp1, "logs", "chest_x_ray", "split_0", "stdout.txt")).read()
+    assert "Traceback" not in txt and "Testing procedure finished" in txt, txt
+    for key in ("Majority voting accuracy for MC:", "ECE:", "Average correct PIW per class:", "Average incorrect variances per class:"):
+        assert key in r.stdout, (key, r.stdout[-1500:])
+    # (ii) in-process, the batch loop observed
+    seen = {"raw": [], "targets": [], "runner": None}
+    orig_shard, orig_atk = runner_mod.Diffusion.shard_of_batch, runner_mod.Diffusion.test_atk
+
+    def spy_shard(self, images_raw, lo, hi):
+        seen["raw"].append(images_raw.clone())
+        return orig_shard(self, images_raw, lo, hi)
+
+    def spy_atk(self, test_loader=None):
+        seen["runner"] = self
+        from nested_diffusion_amd.data import get_test_loader
+        loader = get_test_loader(self.args, self.config)
+        seen["dataset"] = loader.dataset
+        batches = [(x, t) for x, t in loader]
+        seen["targets"] = [t.clone() for _, t in batches]
+        return orig_atk(self, test_loader=batches)
+
+    monkeypatch.setattr(runner_mod.Diffusion, "shard_of_batch", spy_shard)
+    monkeypatch.setattr(runner_mod.Diffusion, "test_atk", spy_atk)
+    argv = flags + ["--config", ypath, "--exp", os.path.join(str(tmp_path), "results_inproc")]
+    assert nd_main.main(argv) == 0
+    out = capsys.readouterr().out
+    assert "Majority voting accuracy for MC:" in out and "ECE:" in out, out
+    log = open(os.path.join(str(tmp_path), "results_inproc", "logs", "chest_x_ray", "split_0", "stdout.txt")).read()
+    assert "Traceback" not in log and "Testing procedure finished" in log, log
+    ds, runner = seen["dataset"], seen["runner"]
+    assert ds.classes == ["NORMAL", "PNEUMONIA"] and len(ds) == 7                       # notes.txt is not a sample
+    assert [os.path.basename(p_) for p_, _ in ds.samples] == ["a_same.png", "b_gray.png", "c_big.png", "d_wide.png", "e_tall.png",
+                                                              "f_gray_small.png", "g_last.jpg"]
+    assert len(seen["raw"]) == 7 // B == 2                                              # drop_last: floor(N / B) batches
+    assert all(tuple(x.shape) == (B, 3, 224, 224) and x.dtype == torch.float32 for x in seen["raw"])
+    assert torch.cat(seen["targets"]).tolist() == [0, 0, 0, 0, 1, 1]                    # g_last.jpg (the 7th) never reaches the GPU
+    assert runner.last_probs.shape == (6, 2) and torch.isfinite(runner.last_probs).all()
+    assert torch.allclose(runner.last_probs.sum(1).cpu(), torch.ones(6), atol=1e-5)
+    acc = float(runner.last_report["accuracy"])
+    assert min(abs(acc - k / 6) for k in range(7)) < 1e-6                               # an accuracy over exactly six images
+    # the first batch against the transforms by hand
+    x0 = seen["raw"][0].numpy().astype(np.float64)
+
+    def luma(a):
+        a = a.astype(np.int64)
+        return ((19595 * a[..., 0] + 38470 * a[..., 1] + 7471 * a[..., 2] + 32768) >> 16).astype(np.float64)
+
+    want_same = (luma(px["a_same.png"]) / 255.0).astype(np.float32).astype(np.float64)
+    want_gray = (px["b_gray.png"].astype(np.float64) / 255.0).astype(np.float32).astype(np.float64)    # L -> RGB -> L is the identity
+    for c in range(3):
+        assert np.array_equal(x0[0, c], want_same), c                                   # Grayscale(3): one luma plane, replicated
+        assert np.array_equal(x0[1, c], want_gray), c
+    taps = np.array([1, 3, 3, 1], dtype=np.float64) / 8.0
+
+    def down2(a, axis):                                                                  # output i takes inputs 2i-1 .. 2i+2 (edges renormalised)
+        a = np.moveaxis(a, axis, 0)
+        n = a.shape[0] // 2
+        o = np.zeros((n,) + a.shape[1:])
+        for i in range(n):
+            idx = np.arange(2 * i - 1, 2 * i + 3)
+            ok = (idx >= 0) & (idx < a.shape[0])
+            w = taps[ok] / taps[ok].sum()
+            o[i] = np.tensordot(w, a[idx[ok]], axes=(0, 0))
+        return np.moveaxis(o, 0, axis)
+
+    want_big = down2(np.rint(down2(luma(px["c_big.png"]), 1)), 0) / 255.0            # PIL: horizontal pass (rounded to 8 bits), then vertical
+    err = np.abs(x0[2, 0] - want_big)
+    assert err.max() < 1.5 / 255 and err.mean() < 0.35 / 255, (err.max() * 255, err.mean() * 255)     # each pass rounds to 8 bits
+    assert np.array_equal(x0[2, 0], x0[2, 1]) and np.array_equal(x0[2, 1], x0[2, 2])

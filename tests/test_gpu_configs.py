@@ -77,7 +77,7 @@ def test_config3_real_shape_8_shards_of_32_equal_one_process_of_256(tmp_path):
     """configs[3] at its REAL shape -- batch 256 as 8 ranks x 32 rows at config dims -- against one process holding all 256 rows.
     The two sides cross kernel families: a 32-row shard streams through k_skinny, the 256-row batch goes through the LDS-tiled
     k_cond_gemm.  A GPU box admits at most 6 processes on its card, so the 8 ranks are rehearsed one after the other in ONE
-    process (dist.emulate_rank: same shard bounds, same first-image noise index, same padding / unpadding around the gather; the
+    process (tests/_emulated_dist.py: same shard bounds, same first-image noise index, same padding / unpadding around the gather; the
     collective itself at world 8 runs over gloo in tests/test_dist_gloo.py, over RCCL on the driver's 8-GPU node)."""
     torch.cuda.empty_cache()
     one, eight = str(tmp_path / "w1.pt"), str(tmp_path / "w8.pt")

@@ -136,3 +136,43 @@ def test_reference_mc_trials_20_end_to_end(headline):
     top2 = counts.topk(2, dim=1).values
     safe = (top2[:, 0] - top2[:, 1]) > 2
     assert torch.equal(out["vote"].cpu()[safe], vote[safe])
+
+
+def test_config1_single_member_at_its_own_geometry(headline):
+    """BASELINE configs[1]: K = 1 member, T = 100, B = 32 at config dims (D = 150528, F = H = 4096).  With one member per launch the
+    weight stream deals ONE weight fragment to each of 256 workgroups (k_skinny<MT=2, NF=1, ...>, a different instantiation from the
+    K = 5 launches' 5-6 fragments per workgroup): this puts exactly that geometry -- F = 4096, M = 32, NF = 1, both block modes, its
+    two-stage register pipeline in steady state over 256 k-chunks -- under the oracle.  Member 0 of the fixture: encoder hoist and
+    p_sample_loop (diffusion_utils.py:133-163) launched for the one member, conditioned on mapping MLP 0.
+    Criterion: y_0 within 1e-4 relative, class probabilities within 1e-3 (north_star), vote equal away from ties."""
+    from nested_diffusion_amd import ops
+    runner, host = headline
+    eng = runner.engine
+    plan = eng.step_plan(B, 1)
+    assert plan["kernel"] == "k_skinny" and plan["stream"]["NF"] == 1 and plan["stream"]["MT"] == 2, plan
+    assert plan["stream"]["grid"] == (256, 1, 1), plan
+    assert eng.step_plan(B, K)["stream"]["NF"] == 6                      # the headline launches: 51 workgroups per member, 5-6 fragments
+    g = torch.Generator().manual_seed(277)
+    x = torch.rand(B, 3, 224, 224, generator=g)
+    noise = torch.randn(1, 1, T, B, C, generator=g)                     # oracle layout [K, mc, T, B, C]
+    xd = x.cuda()
+    logits = runner.compute_guiding_prediction(xd, include_full_vit=False)
+    yhat_d = torch.softmax(logits[0], dim=1)[None].contiguous()          # [1, B, C]  (:755-758; y_T_mean = y_0_hat, :762)
+    eng.encode(xd.flatten(1), 0, 1)
+    y0 = eng.sample(yhat_d, yhat_d, noise.reshape(1, T, B, C).cuda(), member0=0, n_members=1, mc=1, T=T)     # [1, B, C]
+    prob_d, vote_d, _ = ops.aggregate(y0.contiguous(), runner.temperature)
+    torch.cuda.synchronize()
+    ref_logits = ref_cpu.compute_guiding_prediction(host["vit"], host["mlps"][:1], x, 12, 12, full_vit=False, share_prefix=True)
+    yhat = [torch.softmax(ref_logits[0], dim=1)]
+    alphas, omabs = ref_cpu.schedule_tables("linear", T, 1e-4, 0.02)
+    raw, vote, prob = ref_cpu.ensemble_predict(host["members"][:1], x.flatten(1), yhat, T, alphas, omabs, noise, runner.temperature, hoist=True)
+    ref = torch.stack(raw)
+    d_y0 = (y0.cpu() - ref).abs().max().item()
+    d_prob = (prob_d.cpu() - prob).abs().max().item()
+    print(f"configs[1] K=1 T={T} B={B}: max |class-prob delta| = {d_prob:.3e}, max |y0 delta| = {d_y0:.3e} (|y0| max {ref.abs().max().item():.2f}); "
+          f"stream plan {plan['stream']}")
+    assert d_y0 < 1e-4 * max(1.0, ref.abs().max().item())
+    assert d_prob <= 1e-3
+    margin = (ref[0].topk(2, dim=1).values[:, 0] - ref[0].topk(2, dim=1).values[:, 1])
+    safe = margin > 10 * d_y0
+    assert safe.sum() >= B - 2 and torch.equal(vote_d.cpu()[safe], vote[safe])

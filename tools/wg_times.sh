@@ -1,3 +1,5 @@
+# Per-workgroup clocks of the step kernels: a debug variant of the WHOLE library (every source of nested_diffusion_amd.build.SOURCES,
+# -DND_WG_TIMING) next to the product one, loaded through ND_LIB_PATH.  Build errors are shown, not swallowed.
 cd $GRAFT_REPO_ROOT
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DND_WG_TIMING nested_diffusion_amd/csrc/nd_skinny_m0.hip nested_diffusion_amd/csrc/nd_skinny_m1.hip nested_diffusion_amd/csrc/nd_skinny_m2.hip nested_diffusion_amd/csrc/nd_sampler.hip nested_diffusion_amd/csrc/nd_ops.hip nested_diffusion_amd/csrc/nd_vit.hip nested_diffusion_amd/csrc/nd_image.hip nested_diffusion_amd/csrc/nd_cond_gemm.hip nested_diffusion_amd/csrc/nd_attention.hip nested_diffusion_amd/csrc/nd_gemm_f32.hip -o /tmp/libnd_hip_dbg.so 2>/dev/null
+python3 -c "from nested_diffusion_amd import build; print(build.build(out='/tmp/libnd_hip_dbg.so', defines=['ND_WG_TIMING']))" || exit 1
 for s in 0 4; do echo "== ND_TAIL_SPLIT=$s"; ND_TAIL_SPLIT=$s ND_LIB_PATH=/tmp/libnd_hip_dbg.so python3 tools/wg_times.py 2>&1 | grep -v amdgpu.ids; done
