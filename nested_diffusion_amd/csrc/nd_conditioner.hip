@@ -12,12 +12,19 @@
 #include <atomic>
 #include <vector>
 #include <cstring>
+#include <cstdlib>
 #include "../../include/nested_diffusion.h"
 
 int nd_set_err(int code, const char* fmt, ...);
 // nd_ops.hip: Classifier.forward on packed activations (one input pack, hidden layers written in streaming order)
 int nd_mlp_chain(const float* x, const void* const* wpk, const float* const* bias, const int* dims, float* const* hid, float* logits,
                  int M, int dtype, void* ws, size_t ws_bytes, void* stream);
+// ... and the same with layers 2..4 of several MLPs sharing launches (their first layers run one by one, each behind its prefix block)
+bool nd_mlp_tail_batchable(const int* dims, int M, int nm, int dtype);
+int nd_mlp_chain_first(const float* x, const void* w1pk, const float* bias1, const int* dims, float* hid0, int M, int dtype, void* ws,
+                       size_t ws_bytes, void* stream);
+int nd_mlp_chain_tail(int nm, const nd_mlp_weights* w, const int* dims, float* const* hid0, float* const* hid1, float* const* hid2, float* logits,
+                      size_t logits_stride, int M, int dtype, void* stream);
 
 static std::atomic<unsigned long long> g_cond_serial{1};
 
@@ -37,7 +44,8 @@ struct nd_cond_s {
     float *cols = nullptr, *tok = nullptr, *mid_tok = nullptr, *h = nullptr, *qkv = nullptr, *att = nullptr, *fc1 = nullptr;
     // ND_DTYPE_F32_SPLIT: frag32b3 images of the GEMM inputs (csrc/nd_b9.hpp): xs = the current [R, kpe | E] input, fc1s = GELU(fc1)
     void *xs = nullptr, *fc1s = nullptr;
-    float* m[3] = {nullptr, nullptr, nullptr};
+    float* m[3] = {nullptr, nullptr, nullptr};       // the mapping MLPs' hidden activations: n_mlps slices of m_stride[l] floats each
+    size_t m_stride[3] = {0, 0, 0};
     void *gemm_ws = nullptr, *lin_ws = nullptr;
     size_t gemm_ws_bytes = 0, lin_ws_bytes = 0;
 };
@@ -92,7 +100,10 @@ static void carve(nd_cond_s* c, char* base, size_t* total) {
         c->fc1 = (float*)take(R * Hd * 4);
         c->xs = c->fc1s = nullptr;
     }
-    for (int i = 0; i < 3; ++i) c->m[i] = (float*)take(((B + 15) / 16 * 16) * (size_t)g.mlp_widths[i] * 4);   // packed: whole 16-row tiles
+    for (int i = 0; i < 3; ++i) {                                     // packed: whole 16-row tiles; one slice per mapping MLP
+        c->m_stride[i] = (((B + 15) / 16 * 16) * (size_t)g.mlp_widths[i] + 63) & ~(size_t)63;
+        c->m[i] = (float*)take((size_t)g.n_mlps * c->m_stride[i] * 4);
+    }
     size_t gw = 0;
     const int rows[2] = {(int)(B * ntok), (int)R};
     for (int r : rows) {
@@ -212,6 +223,7 @@ extern "C" int nd_cond_set_mlp(nd_cond c, int i, const nd_mlp_weights* w) {
     return ND_OK;
 }
 
+#define ND_COND_MAX_BATCHED 8        // = ND_INLINE_DESCS (csrc/nd_common.hpp): members whose descriptors travel by value in one launch
 #define ND_TRY(call)          \
     do {                      \
         int _rc = (call);     \
@@ -282,13 +294,25 @@ int nd_guiding_prediction_first(nd_cond c, const float* images, float* logits_ou
                                 c->gemm_ws_bytes, stream));
     }
     const int dims[5] = {ntok * E, g.mlp_widths[0], g.mlp_widths[1], g.mlp_widths[2], C};
+    // ND_MLP_TAIL_PER_MEMBER=1: every MLP's four layers one after the other (rounds 1-4), the A/B switch of the batched tail
+    const bool batch_tail = n_used <= ND_COND_MAX_BATCHED && nd_mlp_tail_batchable(dims, B, n_used, dt) && !getenv("ND_MLP_TAIL_PER_MEMBER");
     for (int i = 0; i < n_used; ++i) {
         // member i's prefix blocks[0..i] reuse member i-1's tokens (:339-340 recomputes them from patch_embed: same values)
         ND_TRY(vit_block(c, i, c->tok, c->tok, B, ntok, stream));
         // mlps[i](tmp): reshape(-1, 196*768) -> 3 x (Linear, ReLU) -> Linear (mapping/models/mlp.py:23-29)
         const nd_mlp_weights& w = c->mlps[i];
         float* logits = logits_out + (size_t)i * B * C;
-        ND_TRY(nd_mlp_chain(c->tok, w.w_packed, w.bias, dims, c->m, logits, B, dt, c->lin_ws, c->lin_ws_bytes, stream));
+        float* hid[3] = {c->m[0] + (size_t)i * c->m_stride[0], c->m[1] + (size_t)i * c->m_stride[1], c->m[2] + (size_t)i * c->m_stride[2]};
+        // layer 1 (the 150528-wide weight stream) right behind its block; layers 2..4 of all members afterwards in three shared launches
+        if (batch_tail) ND_TRY(nd_mlp_chain_first(c->tok, w.w_packed[0], w.bias[0], dims, hid[0], B, dt, c->lin_ws, c->lin_ws_bytes, stream));
+        else ND_TRY(nd_mlp_chain(c->tok, w.w_packed, w.bias, dims, hid, logits, B, dt, c->lin_ws, c->lin_ws_bytes, stream));
+    }
+    if (batch_tail) {
+        float *h0[ND_COND_MAX_BATCHED], *h1[ND_COND_MAX_BATCHED], *h2[ND_COND_MAX_BATCHED];
+        for (int i = 0; i < n_used; ++i) {
+            h0[i] = c->m[0] + (size_t)i * c->m_stride[0]; h1[i] = c->m[1] + (size_t)i * c->m_stride[1]; h2[i] = c->m[2] + (size_t)i * c->m_stride[2];
+        }
+        ND_TRY(nd_mlp_chain_tail(n_used, c->mlps.data(), dims, h0, h1, h2, logits_out, (size_t)B * C, B, dt, stream));
     }
     // softmax of every condition's logits (:755-758): rows are independent and [n_used][B][C] is contiguous -- one launch, not n_used
     if (yhat_out) ND_TRY(nd_softmax_rows(logits_out, yhat_out, n_used * B, C, stream));

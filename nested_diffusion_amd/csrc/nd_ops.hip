@@ -111,6 +111,51 @@ int nd_mlp_chain(const float* x, const void* const* wpk, const float* const* bia
     return ND_OK;
 }
 
+// The same Classifier.forward for SEVERAL mapping MLPs whose first layers have already run (nd_mlp_chain_first): layers 2..4 of all nm
+// members as THREE launches instead of 3 * nm -- the members' weights differ, their shapes do not, so one k_skinny launch streams the
+// nm weight matrices side by side exactly as a step block streams the K noise estimators' (descriptors by value).  At config dims a
+// single member's layer is 33 MB / 1 MB / 1 KB of weights: launch-latency bound on its own (11 us each, 15 launches per batch).
+// Values are those of the one-member launches up to the dealing of k-chunks to waves (fixed per geometry: reproducible).
+// batchable: every one of the three layers is a plain streaming launch (no split-K, no LDS-tiled form) and nm fits the inline table.
+bool nd_mlp_tail_batchable(const int* dims, int M, int nm, int dtype) {
+    const int half = dtype == ND_DTYPE_F16;
+    if (nm < 2 || nm > ND_INLINE_DESCS) return false;
+    for (int l = 1; l < 4; ++l)
+        if (nd_use_splitk(dims[l]) || nd_cond_gemm_plan(dims[l], dims[l + 1], M, nm, half).use_tile || nd_cond_gemm_plan(dims[l], dims[l + 1], M, 1, half).use_tile)
+            return false;
+    return true;
+}
+
+// layer 1 of one mapping MLP (the 150528-wide split-K stream): hid0 = relu(x W1^T + b1), written packed for layer 2
+int nd_mlp_chain_first(const float* x, const void* w1pk, const float* bias1, const int* dims, float* hid0, int M, int dtype, void* ws,
+                       size_t ws_bytes, void* stream) {
+    const int half = dtype == ND_DTYPE_F16, opk = half ? 2 : 1;
+    if (ws_bytes < nd_linear_workspace_bytes(M, dims[0], dims[1], dtype)) return nd_set_err(ND_ERR_ARG, "mlp chain workspace too small for layer 1");
+    float* xpk = (float*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+    float* part = (float*)((char*)xpk + ((nd_packed_bytes_dt(M, dims[0], half) + 255) & ~(size_t)255));
+    int rc = nd_pack_rows(x, xpk, M, dims[0], dtype, stream);
+    if (rc != ND_OK) return rc;
+    return linear_packed(xpk, (const float*)w1pk, nullptr, bias1, hid0, M, dims[0], dims[1], ND_ACT_RELU, half, opk, part, (hipStream_t)stream);
+}
+
+// layers 2..4 of nm members: hid[l][k] = member k's activation after layer l+1 (packed), logits + k * logits_stride = its output
+int nd_mlp_chain_tail(int nm, const nd_mlp_weights* w, const int* dims, float* const* hid0, float* const* hid1, float* const* hid2, float* logits,
+                      size_t logits_stride, int M, int dtype, void* stream) {
+    const int half = dtype == ND_DTYPE_F16, opk = half ? 2 : 1;
+    if (!nd_mlp_tail_batchable(dims, M, nm, dtype)) return nd_set_err(ND_ERR_ARG, "mlp tail of %d members at %d rows is not batchable", nm, M);
+    float* const* in[3] = {hid0, hid1, hid2};
+    float* const* outp[2] = {hid1, hid2};
+    for (int l = 1; l < 4; ++l) {
+        SkinnyDesc d[ND_INLINE_DESCS];
+        for (int k = 0; k < nm; ++k)
+            d[k] = SkinnyDesc{in[l - 1][k], (const float*)w[k].w_packed[l], nullptr, w[k].bias[l], l < 3 ? outp[l - 1][k] : logits + (size_t)k * logits_stride,
+                              nullptr, nullptr, dims[l], dims[l + 1], 0, l < 3 ? ND_ACT_RELU : ND_ACT_NONE, l < 3 ? opk : 0, 0};
+        HIP_CHECK(nd_launch_skinny_inline(nd_skinny_launch<0>(dims[l], dims[l + 1], M, nm, half), d, nm, M, 0, (hipStream_t)stream));
+    }
+    HIP_CHECK(hipGetLastError());
+    return ND_OK;
+}
+
 // ---- launch-plan introspection (host only; no GPU needed) -------------------------------------
 extern "C" int nd_skinny_plan(int K, int N, int M, int n_members, int dtype, int mode, int* out6) {
     if (!out6) return nd_set_err(ND_ERR_ARG, "out6 is NULL");

@@ -129,17 +129,23 @@ def _vit_and_mlps(embed=128, heads=2, depth=5, img=32, patch=16, K=5, widths=(64
 
 
 @pytest.mark.parametrize("dtype", ["f32", "f16"])
-def test_c_level_conditioner_equals_operator_by_operator_launches_and_the_oracle(dtype):
+def test_c_level_conditioner_equals_operator_by_operator_launches_and_the_oracle(dtype, monkeypatch):
     from nested_diffusion_amd.mapping import Classifier, GuidingConditioner, VisionTransformer
     heads, depth, img = 2, 5, 32
     vp, mlps = _vit_and_mlps(heads=heads, depth=depth, img=img, widths=(64, 32, 32))
     cond = GuidingConditioner(VisionTransformer(vp, heads, dtype=dtype), [Classifier(m, dtype=dtype) for m in mlps])
     x = torch.rand(6, 3, img, img, generator=torch.Generator().manual_seed(5))
+    batched = cond.compute_guiding_prediction(x.cuda(), include_full_vit=True)       # layers 2..4 of the five MLPs in three shared launches
+    monkeypatch.setenv("ND_MLP_TAIL_PER_MEMBER", "1")                                 # every MLP's four layers one after the other
     got = cond.compute_guiding_prediction(x.cuda(), include_full_vit=True)
     py = cond.compute_guiding_prediction_py(x.cuda(), include_full_vit=True)
-    assert len(got) == len(py) == 6
-    for a, b in zip(got, py):
+    monkeypatch.delenv("ND_MLP_TAIL_PER_MEMBER")
+    assert len(got) == len(py) == len(batched) == 6
+    for a, b, c in zip(got, py, batched):
         assert torch.equal(a, b)                                           # same kernels in the same order: bitwise
+        # the shared launches deal the k-chunks to the waves in another order: same values to rounding (fp16 operands: a last-bit
+        # difference of a hidden activation can flip its rounding to fp16, 2^-11 of that value)
+        assert (a - c).abs().max().item() <= (2e-5 if dtype == "f32" else 5e-4) * max(1.0, float(a.abs().max())), dtype
     smaller = cond.compute_guiding_prediction(x[:3].cuda(), include_full_vit=False)      # B below the handle's max_batch
     if dtype == "f32":
         ref = ref_cpu.compute_guiding_prediction(vp, mlps, x, heads, depth, full_vit=True, share_prefix=False)
@@ -168,14 +174,46 @@ def test_conditioner_split_mode_equals_f32_mfma_mode(monkeypatch):
         cond = GuidingConditioner(vit, [Classifier(m) for m in mlps])
         got = cond.compute_guiding_prediction(x, include_full_vit=True)
         assert _lib.load().nd_cond_get_config(cond._h).contents.operand_dtype == (_lib.ND_DTYPE_F32_SPLIT if mode == "b9" else _lib.ND_DTYPE_F32)
-        for a, b in zip(got, cond.compute_guiding_prediction_py(x, include_full_vit=True)):
+        monkeypatch.setenv("ND_MLP_TAIL_PER_MEMBER", "1")             # the launch sequence the operator-by-operator form makes
+        for a, b in zip(cond.compute_guiding_prediction(x, include_full_vit=True), cond.compute_guiding_prediction_py(x, include_full_vit=True)):
             assert torch.equal(a, b), mode
+        monkeypatch.delenv("ND_MLP_TAIL_PER_MEMBER")
         for k in range(6):
             assert (got[k].cpu() - ref[k]).abs().max() < 2e-5 * max(1.0, float(ref[k].abs().max())), (mode, k)
         outs[mode] = got
     for a, b in zip(outs["b9"], outs["mfma_f32"]):
         assert (a - b).abs().max().item() < 2e-5 * max(1.0, float(b.abs().max()))
         assert not torch.equal(a, b)                                  # two kernels, two summation orders: not the same code path
+
+
+@pytest.mark.parametrize("dtype,B,K", [("f32", 32, 5), ("f32", 70, 5), ("f16", 32, 5), ("f32", 5, 2), ("f32", 32, 1), ("f32", 140, 3)])
+def test_mapping_mlp_tails_share_launches(dtype, B, K, monkeypatch):
+    """mapping/models/mlp.py:23-29 for the K members of compute_guiding_prediction (:336-345) at the reference's layer widths
+    (4096 -> 2048 -> 128 -> classes): layer 1 of each MLP runs behind its prefix block, layers 2..4 of ALL members as three launches of
+    K weight matrices each (nd_mlp_chain_tail) instead of 3 K launches.  Against the per-member sequence (ND_MLP_TAIL_PER_MEMBER=1) the
+    logits agree to fp32 rounding (the k-chunks are dealt to the waves in another order), against the oracle within its tolerance.
+    K = 1 and more than 128 rows (the LDS-tiled form of a layer) keep the per-member sequence: identical bits."""
+    from nested_diffusion_amd.mapping import Classifier, GuidingConditioner, VisionTransformer
+    heads, depth, img = 2, 5, 32
+    vp, mlps = _vit_and_mlps(heads=heads, depth=depth, img=img, K=K, widths=(4096, 2048, 128))
+    cond = GuidingConditioner(VisionTransformer(vp, heads, dtype=dtype), [Classifier(m, dtype=dtype) for m in mlps])
+    x = torch.rand(B, 3, img, img, generator=torch.Generator().manual_seed(15))
+    shared = cond.compute_guiding_prediction(x.cuda(), include_full_vit=False)
+    again = cond.compute_guiding_prediction(x.cuda(), include_full_vit=False)
+    monkeypatch.setenv("ND_MLP_TAIL_PER_MEMBER", "1")
+    single = cond.compute_guiding_prediction(x.cuda(), include_full_vit=False)
+    monkeypatch.delenv("ND_MLP_TAIL_PER_MEMBER")
+    assert len(shared) == len(single) == K
+    for k in range(K):
+        assert torch.equal(shared[k], again[k])                                          # reproducible
+        # (fp16 operands: a last-bit difference of a hidden activation can flip its rounding to fp16, 2^-11 of that value)
+        assert (shared[k] - single[k]).abs().max().item() <= (2e-5 if dtype == "f32" else 5e-4) * max(1.0, float(single[k].abs().max())), k
+        if K == 1 or B > 128:
+            assert torch.equal(shared[k], single[k])
+    if dtype == "f32":
+        ref = ref_cpu.compute_guiding_prediction(vp, mlps, x, heads, depth, full_vit=False, share_prefix=True)
+        for k in range(K):
+            assert (shared[k].cpu() - ref[k]).abs().max() < 2e-5 * max(1.0, float(ref[k].abs().max())), k
 
 
 def test_conditioner_driven_through_ctypes_only():

@@ -248,6 +248,28 @@ __global__ __launch_bounds__(64 * WN * WM) void k_gemm_b9v2(const bf16x8* __rest
     const unsigned long long t_entry = __builtin_amdgcn_s_memrealtime();
     // EXPERIMENT: de-phase the two workgroups that share a CU (they start together and then run in lockstep, so their prologues and
     // epilogues -- during which a workgroup issues no MFMA -- coincide): the second residency wave of the initial dispatch waits
+    // EXPERIMENT (round 5, UB_PRIO): wave priorities (s_setprio) against the oldest-first issue arbitration that lets one of the two
+    // co-resident workgroups run at its solo rate while the other only fills gaps.  stagger_ticks < 0 selects a scheme:
+    //   -1  by SIMD pair: a workgroup's waves on SIMDs {0,1} are high when it arrived on its CU as an even arrival, on {2,3} when odd
+    //   -2  finish boost: a wave raises its priority for the last quarter of its tile's K-steps
+    //   -3  alternating: priority flips every K-step, in opposite phase for even and odd arrivals
+    //   -4  start boost: high priority for the first quarter of the K-steps (a fresh tile catches up with its partner)
+    unsigned arrival = 0;
+    if (stagger_ticks < 0) {
+        __shared__ unsigned s_arr;
+        if (threadIdx.x == 0) {
+            const unsigned hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));          // HW_REG_HW_ID
+            const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 15u;    // HW_REG_XCC_ID
+            const unsigned key = xcc * 256 + ((hw >> 13) & 7) * 32 + ((hw >> 12) & 1) * 16 + ((hw >> 8) & 15);
+            s_arr = atomicAdd(reinterpret_cast<unsigned*>(clk) + 2 * 65536 + key, 1u);
+        }
+        __syncthreads();
+        arrival = __builtin_amdgcn_readfirstlane(s_arr);
+        if (stagger_ticks == -1) {
+            const unsigned simd = (__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)) >> 4) & 3u;
+            if ((((simd >> 1) ^ arrival) & 1u) == 0) __builtin_amdgcn_s_setprio(2);
+        }
+    }
     if (stagger_ticks > 0 && blockIdx.x < 512) {
         // every other ARRIVAL on a CU waits (per-CU arrival counters keyed by XCC_ID / SE_ID / CU_ID, never reset: parity alternates)
         __shared__ unsigned s_order;
@@ -336,6 +358,12 @@ __global__ __launch_bounds__(64 * WN * WM) void k_gemm_b9v2(const bf16x8* __rest
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (s + u < nk) {
+                if (stagger_ticks < -1) {
+                    const int step = s + u;
+                    if (stagger_ticks == -2) { if (step == nk - nk / 4) __builtin_amdgcn_s_setprio(3); }
+                    else if (stagger_ticks == -3) { if ((step + (int)arrival) & 1) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0); }
+                    else if (stagger_ticks == -4) { if (step == 0) __builtin_amdgcn_s_setprio(3); else if (step == nk / 4) __builtin_amdgcn_s_setprio(0); }
+                }
                 V2_SYNC()
                 if (SCHED == 0) { V2_STAGE(u % NS, min(s + u + NS, nk - 1)) V2_READ((u + 1) & 1, (u + 1) % NS) }
                 else { V2_READ((u + 1) & 1, (u + 1) % NS) V2_STAGE(u % NS, min(s + u + NS, nk - 1)) }
@@ -640,7 +668,8 @@ static void run_gemm2(const Shape& sh, const float* dW, const float* dX, bf16x8*
         printf("\n");
     }
     const double ideal = 9.0 * FA * FB * 16.0 * occ * (NW / 4);
-    if (stagger_ticks) printf("  [second residency wave delayed by %.1f us]", stagger_ticks * 0.01);
+    if (stagger_ticks > 0) printf("  [second residency wave delayed by %.1f us]", stagger_ticks * 0.01);
+    if (stagger_ticks < 0) printf("  [wave priorities, scheme %d]", -stagger_ticks);
     printf("  v2 tile %3dx%-3d %d waves NS=%d sched %d  %d wg/CU  %5d tiles = %d whole + %d x %d slabs | gemm %7.1f us = %6.1f TF-eq | vs library %.0f us: %.2fx"
            " | %.0f cyc/step (ratio %.2f) %.2f GHz | err %.2e\n",
            BN, BM, NW, NS, SCHED, occ, tiles, n_full, rem, split, us_g, flop / us_g * 1e-6, sh.yard_us, sh.yard_us / us_g, cyc / nkb, cyc / nkb / ideal, ghz,
@@ -710,6 +739,12 @@ int main(int argc, char** argv) {
             run_gemm2<4, 2, 2, 2, 2, 0>(sh, dW, dX, wP, xP, dOut, hW, hX, ncu, false);
             if (getenv("UB_STAGGER")) {
                 for (int tk : {500, 1000, 1500, 2000}) run_gemm2<4, 2, 2, 2, 2, 0>(sh, dW, dX, wP, xP, dOut, hW, hX, ncu, false, tk);
+            }
+            if (getenv("UB_PRIO")) {
+                for (int sc : {-1, -2, -3, -4}) run_gemm2<4, 2, 2, 2, 2, 0>(sh, dW, dX, wP, xP, dOut, hW, hX, ncu, false, sc);
+                run_gemm2<4, 2, 2, 2, 2, 0>(sh, dW, dX, wP, xP, dOut, hW, hX, ncu, false);      // the unprioritised form again, same clock state
+                CK(hipFree(dW)); CK(hipFree(dX)); CK(hipFree(dOut)); CK(hipFree(wP)); CK(hipFree(xP));
+                continue;
             }
             run_gemm2<4, 2, 2, 2, 2, 0>(sh, dW, dX, wP, xP, dOut, hW, hX, ncu, true);
             run_gemm2<4, 2, 2, 4, 2, 0>(sh, dW, dX, wP, xP, dOut, hW, hX, ncu, true);
