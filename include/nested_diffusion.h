@@ -234,6 +234,19 @@ int nd_attention(const float *qkv_dev, float *out_dev, int B, int N, int heads, 
 /* The fp32 attention with its result written as the frag32b3 image of [B*N, heads*d] (the input of the proj nd_gemm_split). */
 int nd_attention_split(const float *qkv_dev, void *out_split_dev, int B, int N, int heads, int d, void *stream);
 
+/* The same attention with BOTH contractions on the bf16 matrix pipe, exact fp32 products (timm 0.4.12 Attention.forward; call sites
+ * classification_train_separately.py:339-340).  Its operands are "qkv images": per (image, head) the q and k rows as frag32b3 blocks and
+ * v transposed (layout: B9AttLayout, csrc/nd_b9.hpp), written directly by the qkv Linear's epilogue:
+ *   nd_qkv_images_supported  1 where the form applies: N % 4 == 0, N <= 256, heads * 64 a multiple of 128
+ *   nd_qkv_images_bytes      size of the image buffer for B images of N tokens
+ *   nd_gemm_split_qkv        qkv Linear: x_split_dev image of [B*N, K], w_split_dev image of the [3*heads*64, K] weight, bias [3*heads*64]
+ *   nd_attention_images      softmax(q k^T / 8) v from the images; out_dev fp32 [B*N, heads*64] or (out_is_split) its frag32b3 image */
+int nd_qkv_images_supported(int N, int heads);
+size_t nd_qkv_images_bytes(int B, int N, int heads);
+int nd_gemm_split_qkv(const void *x_split_dev, const void *w_split_dev, const float *bias_dev, void *qkv_images_dev, int B, int N, int heads,
+                      int K, void *stream);
+int nd_attention_images(const void *qkv_images_dev, void *out_dev, int out_is_split, int B, int N, int heads, void *stream);
+
 /* PatchEmbed im2col: img [B, Cin, Himg, Wimg] NCHW -> cols [B * (Himg/p) * (Wimg/p), Cin*p*p] so that
  * Conv2d(k=p, s=p) becomes nd_gemm_bias_act with the conv weight viewed [embed, Cin*p*p]. */
 int nd_patchify(const float *img_dev, float *cols_dev, int B, int Cin, int Himg, int Wimg, int p, void *stream);

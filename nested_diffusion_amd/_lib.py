@@ -138,6 +138,10 @@ SIGNATURES = {
     "nd_layernorm_split": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "nd_attention": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "nd_attention_split": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "nd_qkv_images_supported": (_i, [_i, _i]),
+    "nd_qkv_images_bytes": (_sz, [_i, _i, _i]),
+    "nd_gemm_split_qkv": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "nd_attention_images": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "nd_patchify": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "nd_patchify_split": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "nd_softmax_rows": (_i, [_vp, _vp, _i, _i, _vp]),

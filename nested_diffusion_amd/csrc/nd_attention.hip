@@ -245,6 +245,352 @@ __global__ __launch_bounds__(256) void k_attention_ring(const float* __restrict_
     ATT_STAMP(13)
 }
 
+
+// =================================================================================================================================
+// bf16 x 9 form (round 5): both contractions on the bf16 matrix pipe with exact fp32 products (csrc/nd_b9.hpp) -- the last MFMA kernel
+// of the path that still ran on v_mfma_f32_16x16x4_f32 (1/16 of the bf16 rate).  Operands are the per-(image, head) "qkv images" the
+// qkv Linear's epilogue writes (nd_gemm_split_qkv; layout: B9AttLayout in nd_b9.hpp): Q and K as plain frag32b3 blocks (k = d), V
+// TRANSPOSED (k = key, the keys of a 32-block in the order the score accumulators hold them), so nothing is split or transposed here
+// except the probabilities, which are split in registers after the fp32 softmax:
+//     S[key][q]  = sum_d K[key][d] Q[q][d]         18 MFMAs per (16 keys x 16 queries) = 288 matrix-pipe cycles (f32 form: 512)
+//     O^T[d][q]  = sum_key V^T[d][key] P[q][key]   9 MFMAs per (16 d x 16 queries x 32 keys)            (1008 against 1664 per q fragment)
+// A workgroup is four waves (one per SIMD) owning up to EIGHT query fragments of one (image, head) -- two per wave, so every K / V
+// operand read from LDS feeds two fragments' MFMAs (one fragment per wave would keep the LDS 2/3 busy with operand reads alone: 6
+// ds_read_b128 per 18 MFMAs on each of four SIMDs) -- ceil(NF / 8) workgroups per head (7 + 6 fragments at N = 196).  K and then V^T
+// pass through a two-slot LDS ring in tiles of 4 key fragments / 2 key blocks (24 KiB each; 48 KiB and <= 256 VGPRs: two workgroups per CU), brought by LDS-DMA exactly as in the
+// ring kernel above (inline-asm issue, counted waits, two barriers per tile).  Softmax: the same exact two-pass form in fp32.
+// Keys past N: their scores are replaced by select (whatever the never-written rows of the K image hold), their V^T columns are zeroed
+// in registers (0 x NaN would poison the sum), query rows past N are never stored.
+template <typename F, int... Ts>
+__device__ __forceinline__ void run_steps(F& step, std::integer_sequence<int, Ts...>) { (step(std::integral_constant<int, Ts>{}), ...); }
+
+__device__ __forceinline__ bf16x8 nd_ld_b8(const bf16x8* p) { return *(const __attribute__((address_space(1))) bf16x8*)p; }
+
+template <int NF>
+__global__ __launch_bounds__(256, 2) void k_attention_b9(const bf16x8* __restrict__ att, float* __restrict__ out, int B, int N, int heads, int QG,
+                                                      int split_out) {
+    constexpr int NKB = (NF + 1) / 2;
+#ifndef ND_AB9_TFK
+#define ND_AB9_TFK 4
+#endif
+#ifndef ND_AB9_TKV
+#define ND_AB9_TKV 2
+#endif
+#ifndef ND_AB9_NS
+#define ND_AB9_NS 2
+#endif
+#ifndef ND_AB9_ABL          // timing ablations (WRONG results; variant builds of tools/ only): 1 no softmax, 2 no P split, 4 no score MFMAs,
+#define ND_AB9_ABL 0        // 8 no P V MFMAs, 16 operand reads only once per tile, 32 no LDS-DMA after tile 0
+#endif
+    constexpr int TFK = NF < ND_AB9_TFK ? NF : ND_AB9_TFK;     // key fragments per K tile (6 KiB each)
+    constexpr int TKV = NKB < ND_AB9_TKV ? NKB : ND_AB9_TKV;   // 32-key blocks per V^T tile (4 d-fragments x 3 KiB each)
+    constexpr int NTK = (NF + TFK - 1) / TFK, NTV = (NKB + TKV - 1) / TKV, NTT = NTK + NTV;
+    constexpr int SLOT = (TFK * 6 > TKV * 12 ? TFK * 6 : TKV * 12);      // 1 KiB pieces per slot
+    constexpr int NS = ND_AB9_NS;                              // ring slots
+    extern __shared__ __attribute__((aligned(16))) bf16x8 smem[];        // [NS][SLOT][64]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int bid = blockIdx.x;
+    {
+        const int total = gridDim.x, q = total / 8, r = total % 8, xcd = bid % 8, loc = bid / 8;      // a head's workgroups share an XCD
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int bh = bid / QG, qg = bid - bh * QG;
+    const int b = bh / heads, hd = bh - b * heads;
+    const int base_n = NF / QG, rem_n = NF - base_n * QG;
+    const int nq = base_n + (qg < rem_n ? 1 : 0);                  // query fragments of this workgroup (<= 8)
+    const int qf0 = qg * base_n + min(qg, rem_n);
+    const int njw = wave + 4 < nq ? 2 : (wave < nq ? 1 : 0);       // fragments of this wave: qf0 + wave (+ 4)
+    const int g = lane >> 4, li = lane & 15;
+    const B9AttLayout al{N, heads};
+    const bf16x8* rec = att + (size_t)bh * al.units();
+    const bf16x8* qimg = rec;
+    const bf16x8* kimg = rec + (size_t)al.k_block0() * B9_BLOCK_UNITS;
+    const bf16x8* vimg = rec + (size_t)al.v_block0() * B9_BLOCK_UNITS;
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) bf16x8*)smem;
+    const unsigned voff = (unsigned)lane * 16u;
+
+    // tile T (K tiles first) -> slot T & 1.  Every wave issues exactly NPW(T) pieces per tile (the last ones re-issue the tile's last
+    // piece: same bytes to the same place), which is what the counted waits rely on.
+    auto stage = [&](auto tc) {
+        constexpr int T = decltype(tc)::value;
+        if constexpr ((ND_AB9_ABL & 32) && T > 0) return;
+        if constexpr (T < NTK) {
+            constexpr int F0 = T * TFK, NFT = (NF - F0 < TFK ? NF - F0 : TFK), NPC = NFT * 6, NPW = (NPC + 3) / 4;
+#pragma unroll
+            for (int u = 0; u < NPW; ++u) {
+                const int pc = min(wave * NPW + u, NPC - 1);
+                nd_lds_dma16(reinterpret_cast<const float*>(kimg + (size_t)(F0 * 6 + pc) * 64), voff, lds0 + (unsigned)(((T % NS) * SLOT + pc) * 1024));
+            }
+        } else {
+            constexpr int KB0 = (T - NTK) * TKV, NKT = (NKB - KB0 < TKV ? NKB - KB0 : TKV), NPC = NKT * 12, NPW = (NPC + 3) / 4;
+#pragma unroll
+            for (int u = 0; u < NPW; ++u) {
+                const int pc = min(wave * NPW + u, NPC - 1);
+                const int df = pc / (3 * NKT), kl = (pc / 3) % NKT, pl = pc % 3;             // LDS order [df][kl][plane]
+                nd_lds_dma16(reinterpret_cast<const float*>(vimg + (size_t)((df * NKB + KB0 + kl) * 3 + pl) * 64), voff,
+                             lds0 + (unsigned)(((T % NS) * SLOT + pc) * 1024));
+            }
+        }
+    };
+    auto pieces_per_wave = [](int T) constexpr {
+        if (T >= NTT || ((ND_AB9_ABL & 32) && T > 0)) return 0;
+        if (T < NTK) { const int f0 = T * TFK, nft = NF - f0 < TFK ? NF - f0 : TFK; return (nft * 6 + 3) / 4; }
+        const int kb0 = (T - NTK) * TKV, nkt = NKB - kb0 < TKV ? NKB - kb0 : TKV;
+        return (nkt * 12 + 3) / 4;
+    };
+
+    auto body = [&](auto njc) {
+        constexpr int NJ = decltype(njc)::value, NJA = NJ > 0 ? NJ : 1;
+        // this wave's query operands straight from the image (B operand of the score MFMAs: rows = queries, k = d), requested FIRST, then
+        // tile 0; both are waited for together, the registers are handed to the compiler as defined by an asm, and only then are the
+        // other tiles of the ring requested: the compiler does not see the inline-asm LDS-DMAs in vmcnt, so its own wait before the
+        // first use of a loaded register is vmcnt(0) -- which must not find tiles 1 .. NS-1 in flight.
+        bf16x8 qr[NJA][2][3];
+#pragma unroll
+        for (int j = 0; j < NJA; ++j) {
+            const int qfj = min(qf0 + wave + 4 * j, NF - 1);
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) qr[j][c][pl] = nd_ld_b8(qimg + (size_t)((qfj * 2 + c) * 3 + pl) * 64 + lane);
+        }
+        stage(std::integral_constant<int, 0>{});
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < NJA; ++j)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) asm volatile("" : "+v"(qr[j][c][pl]));
+        if constexpr (NTT > 1) stage(std::integral_constant<int, 1>{});
+        if constexpr (NS > 2 && NTT > 2) stage(std::integral_constant<int, 2>{});
+        if constexpr (NS > 3 && NTT > 3) stage(std::integral_constant<int, 3>{});
+        f32x4 s[NJA][NF];
+#pragma unroll
+        for (int j = 0; j < NJA; ++j)
+#pragma unroll
+            for (int f = 0; f < NF; ++f) s[j][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 o[NJA][4];
+#pragma unroll
+        for (int j = 0; j < NJA; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[j][e] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float inv[NJA];
+#pragma unroll
+        for (int j = 0; j < NJA; ++j) inv[j] = 0.f;
+
+        // scores of one K tile in steps of (key fragment, half of d): 3 operand reads (of the NEXT step) dealt between 9 NJ MFMAs (smallest
+        // pair products first, fixed order); consecutive MFMAs alternate between the wave's query fragments
+        auto scores = [&](auto tc) {
+            constexpr int T = decltype(tc)::value;
+            constexpr int F0 = T * TFK, NFT = (NF - F0 < TFK ? NF - F0 : TFK), NST = 2 * NFT;
+            const bf16x8* sk = smem + (size_t)(T % NS) * SLOT * 64 + lane;
+            bf16x8 kr[2][3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) kr[0][pl] = sk[pl * 64];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int st = 0; st < NST; ++st) {
+                const int fl = st >> 1, c = st & 1;
+                if (st + 1 < NST && !(ND_AB9_ABL & 16)) {
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) kr[(st + 1) & 1][pl] = sk[((st + 1) * 3 + pl) * 64];       // block (fl, c) = piece run 3 (2 fl + c)
+                }
+#define AB9_S(pp, qq)                                                                                                                  \
+                _Pragma("unroll") for (int j = 0; j < NJA; ++j)                                                                        \
+                    s[j][F0 + fl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kr[(ND_AB9_ABL & 16) ? 0 : (st & 1)][pp], qr[j][c][qq], s[j][F0 + fl], 0, 0, 0);
+                if constexpr (!(ND_AB9_ABL & 4)) { AB9_S(2, 2) AB9_S(2, 1) AB9_S(1, 2) AB9_S(2, 0) AB9_S(0, 2) AB9_S(1, 1) AB9_S(1, 0) AB9_S(0, 1) AB9_S(0, 0) }
+#undef AB9_S
+                if (st + 1 < NST && !(ND_AB9_ABL & (4 | 16))) {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 3 * NJA, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        // exact two-pass softmax over the keys, per query column (lane & 15): in-lane over (f, r), across the 4 lane groups by xor 16 / 32.
+        // One fragment at a time (scheduling barriers): left alone, the scheduler interleaves all 26 fragments' exponentials for ILP and
+        // spills hundreds of registers at the two-waves-per-SIMD budget.  Only the last fragment can hold keys past N.
+        auto softmax = [&]() {
+            const float scale = 0.125f;      // 64^-0.5
+#pragma unroll
+            for (int j = 0; j < NJA; ++j) {
+                float mx = -1.0e30f;
+#pragma unroll
+                for (int f = 0; f < NF; ++f) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float v = s[j][f][r] * scale;
+                        if (f == NF - 1) v = 16 * f + 4 * g + r < N ? v : -1.0e30f;      // finite stand-in for -inf: exp -> exactly 0
+                        s[j][f][r] = v;
+                        mx = fmaxf(mx, v);
+                    }
+                    asm volatile("" : "+v"(s[j][f]));           // (ordered like the barriers: keeps instruction selection from batching fragments)
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                float sum = 0.f;
+#pragma unroll
+                for (int f = 0; f < NF; ++f) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float pe = nd_exp_neg(s[j][f][r] - mx);
+                        s[j][f][r] = pe;
+                        sum += pe;
+                    }
+                    asm volatile("" : "+v"(s[j][f]));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                sum += __shfl_xor(sum, 16, 64);
+                sum += __shfl_xor(sum, 32, 64);
+                inv[j] = 1.0f / sum;
+            }
+        };
+        // which of a lane's 8 k-slots of the LAST key block hold keys < N (the rest of that V^T block was never written): AND masks per
+        // 32-bit register (two bf16 each)
+        uint32_t vmask[4];
+#pragma unroll
+        for (int w2 = 0; w2 < 4; ++w2) {
+            const int e0 = 2 * w2, e1 = 2 * w2 + 1;
+            const int k0 = 32 * (NKB - 1) + 16 * (e0 >> 2) + 4 * g + (e0 & 3), k1 = 32 * (NKB - 1) + 16 * (e1 >> 2) + 4 * g + (e1 & 3);
+            vmask[w2] = (k0 < N ? 0x0000ffffu : 0u) | (k1 < N ? 0xffff0000u : 0u);
+        }
+        // O^T += V^T P over one V^T tile in steps of (key block, d fragment): 3 operand reads (of the next step) between 9 NJ MFMAs; the
+        // probabilities of a key block are normalised (as torch: softmax, then @ v) and split into their three bf16 pieces per block
+        auto pv = [&](auto tc) {
+            constexpr int T = decltype(tc)::value;
+            constexpr int KB0 = (T - NTK) * TKV, NKT = (NKB - KB0 < TKV ? NKB - KB0 : TKV), NST = 4 * NKT;
+            const bf16x8* sv = smem + (size_t)(T % NS) * SLOT * 64 + lane;
+            bf16x8 vr[2][3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) vr[0][pl] = sv[pl * 64];                       // (kl = 0, df = 0)
+            __builtin_amdgcn_sched_barrier(0);
+            bf16x8 pr[NJA][3];
+#pragma unroll
+            for (int st = 0; st < NST; ++st) {
+                const int kl = st >> 2, df = st & 3, kb = KB0 + kl;
+                if (df == 0 && !((ND_AB9_ABL & 2) && st > 0)) {
+#pragma unroll
+                    for (int j = 0; j < NJA; ++j) {          // the block's probabilities become visible to the compiler only now (see the pin below)
+                        asm volatile("" : "+v"(s[j][2 * kb]));
+                        if (2 * kb + 1 < NF) asm volatile("" : "+v"(s[j][2 * kb + 1]));
+                    }
+#pragma unroll
+                    for (int j = 0; j < NJA; ++j)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const int f = 2 * kb + (e >> 2);
+                            const float pn = f < NF ? s[j][f < NF ? f : NF - 1][e & 3] * inv[j] : 0.f;
+                            // the exact three-piece split of nd_b9_split without its infinity guard: a probability is in [0, 1]
+                            const __bf16 h1 = (__bf16)pn;
+                            const float r1 = pn - (float)h1;
+                            const __bf16 h2 = (__bf16)r1;
+                            const __bf16 h3 = (__bf16)(r1 - (float)h2);
+                            pr[j][0][e] = h1; pr[j][1][e] = h2; pr[j][2][e] = h3;
+                        }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (st + 1 < NST && !(ND_AB9_ABL & 16)) {
+                    const int kl1 = (st + 1) >> 2, df1 = (st + 1) & 3;
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) vr[(st + 1) & 1][pl] = sv[((df1 * NKT + kl1) * 3 + pl) * 64];
+                }
+                if (kb == NKB - 1) {           // (no run-time condition here: a branch inside the tile sequence lets the compiler sink the MFMAs below the barriers)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) {
+                        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                        u32x4 t = __builtin_bit_cast(u32x4, vr[st & 1][pl]);
+                        t[0] &= vmask[0]; t[1] &= vmask[1]; t[2] &= vmask[2]; t[3] &= vmask[3];
+                        vr[st & 1][pl] = __builtin_bit_cast(bf16x8, t);
+                    }
+                }
+#define AB9_O(pp, qq)                                                                                                                  \
+                _Pragma("unroll") for (int j = 0; j < NJA; ++j)                                                                        \
+                    o[j][df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vr[(ND_AB9_ABL & 16) ? 0 : (st & 1)][pp], pr[j][qq], o[j][df], 0, 0, 0);
+                if constexpr (!(ND_AB9_ABL & 8)) { AB9_O(2, 2) AB9_O(2, 1) AB9_O(1, 2) AB9_O(2, 0) AB9_O(0, 2) AB9_O(1, 1) AB9_O(1, 0) AB9_O(0, 1) AB9_O(0, 0) }
+#undef AB9_O
+                // pin the step's MFMAs HERE: they are pure register operations whose results are only stored at the very end, and instruction
+                // selection otherwise emits the whole P V chain behind the last barrier -- with every V^T operand of every tile held (spilled)
+                // until then.  An empty volatile asm that takes and returns the accumulators is ordered with the barriers.
+#pragma unroll
+                for (int j = 0; j < NJA; ++j) asm volatile("" : "+v"(o[j][df]));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+
+        auto step = [&](auto tc) {
+            constexpr int T = decltype(tc)::value;
+            // everything up to tile T has landed: all that may still be in flight are the pieces of the NS - 1 tiles after it
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(pieces_per_wave(T + 1) + (NS > 2 ? pieces_per_wave(T + 2) : 0) + (NS > 3 ? pieces_per_wave(T + 3) : 0)) : "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (NJ > 0) {
+                if constexpr (T < NTK) scores(tc);
+                else pv(tc);
+            }
+            if constexpr (T + NS < NTT) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();                          // every wave is done reading slot T % NS
+                __builtin_amdgcn_sched_barrier(0);
+                stage(std::integral_constant<int, T + NS>{});
+            }
+            if constexpr (NJ > 0 && T == NTK - 1 && !(ND_AB9_ABL & 1)) softmax();          // under the landing of the first V^T tiles
+        };
+        run_steps(step, std::make_integer_sequence<int, NTT>{});
+
+        if constexpr (NJ > 0) {
+            // o[j][df][r] = O[q = 16 qf + (lane & 15)][d = 16 df + 4 g + r]
+            const int Cm = heads * 64;
+#pragma unroll
+            for (int j = 0; j < NJA; ++j) {
+                const int qo = (qf0 + wave + 4 * j) * 16 + li;
+                if (qo < N) {
+#pragma unroll
+                    for (int df = 0; df < 4; ++df) {
+                        if (split_out)
+                            nd_b9_store4(reinterpret_cast<bf16x8*>(out), Cm >> 5, b * N + qo, hd * 64 + 16 * df + 4 * g, o[j][df][0], o[j][df][1], o[j][df][2],
+                                         o[j][df][3]);
+                        else
+                            *reinterpret_cast<float4*>(out + ((size_t)b * N + qo) * Cm + (size_t)hd * 64 + 16 * df + 4 * g) =
+                                make_float4(o[j][df][0], o[j][df][1], o[j][df][2], o[j][df][3]);
+                    }
+                }
+            }
+        }
+    };
+    if (njw == 2) body(std::integral_constant<int, 2>{});
+    else if (njw == 1) body(std::integral_constant<int, 1>{});
+    else body(std::integral_constant<int, 0>{});
+}
+
+template <int NF>
+static hipError_t launch_attention_b9(const void* att, float* out, int B, int N, int heads, int split_out, hipStream_t st) {
+    const int QG = (NF + 7) / 8;
+    constexpr int NKB = (NF + 1) / 2, TFK = NF < ND_AB9_TFK ? NF : ND_AB9_TFK, TKV = NKB < ND_AB9_TKV ? NKB : ND_AB9_TKV;
+    constexpr size_t lds = (size_t)ND_AB9_NS * (TFK * 6 > TKV * 12 ? TFK * 6 : TKV * 12) * 1024;
+    if (lds > 64 * 1024) {
+        hipError_t e = nd_allow_dynamic_lds((const void*)k_attention_b9<NF>, lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((k_attention_b9<NF>), dim3(B * heads * QG), dim3(256), lds, st, (const bf16x8*)att, out, B, N, heads, QG, split_out);
+    return hipGetLastError();
+}
+
+hipError_t nd_launch_attention_b9(const void* att, float* out, int B, int N, int heads, int split_out, hipStream_t st) {
+    switch ((N + 15) / 16) {
+#define AB_CASE(NFV) case NFV: return launch_attention_b9<NFV>(att, out, B, N, heads, split_out, st);
+        AB_CASE(1) AB_CASE(2) AB_CASE(3) AB_CASE(4) AB_CASE(5) AB_CASE(6) AB_CASE(7) AB_CASE(8)
+        AB_CASE(9) AB_CASE(10) AB_CASE(11) AB_CASE(12) AB_CASE(13) AB_CASE(14) AB_CASE(15) AB_CASE(16)
+#undef AB_CASE
+    }
+    return hipErrorInvalidValue;
+}
+
 template <int NF>
 static hipError_t launch_attention_ring(const float* qkv, float* out, int B, int N, int heads, int split_out, hipStream_t st) {
     // tiles per operand: 3 where that leaves whole tiles to stream (NF >= 6), else 2 / 1

@@ -61,6 +61,40 @@ __device__ __forceinline__ void nd_b9_store4(bf16x8* img, int nkb, int r, int k,
     *(__attribute__((address_space(1))) bf16x4*)(q + 4 * 64) = p3;
 }
 
+// ---- "qkv images": the attention operands of one (image, head), written by the qkv GEMM's epilogue (nd_gemm_b9.hip, ATT form) and
+// read by k_attention_b9 (nd_attention.hip).  One record per (image b, head h) at 16-byte-unit offset (b*heads + h) * units():
+//   Q   nfq x 2 blocks   block (f, c) = (16 query rows of fragment f) x (d = 32c .. 32c+31): plain frag32b3 blocks, k = d
+//   K   nfq x 2 blocks   the same for the keys
+//   V^T 4 x nkb blocks   block (df, kb) = (d = 16 df .. +15) x (32 keys of block kb), k = key, the keys of a block PERMUTED: position
+//                        (lane group g, element e) of a plane holds key 32 kb + 16 (e >> 2) + 4 g + (e & 3) -- the two runs of four
+//                        keys whose scores a lane of the attention kernel already holds in score fragments 2 kb and 2 kb + 1
+//                        (S[key = 16 f + 4 g + r][q]), so the probabilities feed the P V MFMA without any cross-lane movement.
+// nfq = ceil(ntok / 16), nkb = ceil(ntok / 32).  Rows / keys past ntok are never written (whatever the buffer held stays there): the
+// attention kernel masks them (scores by select, V operands by zeroing) and never stores their outputs.
+struct B9AttLayout {
+    int ntok, heads;
+    __host__ __device__ int nfq() const { return (ntok + 15) >> 4; }
+    __host__ __device__ int nkb() const { return (ntok + 31) >> 5; }
+    __host__ __device__ int q_block0() const { return 0; }
+    __host__ __device__ int k_block0() const { return 2 * nfq(); }
+    __host__ __device__ int v_block0() const { return 4 * nfq(); }
+    __host__ __device__ size_t units() const { return (size_t)(4 * nfq() + 4 * nkb()) * B9_BLOCK_UNITS; }
+};
+
+// 4 values as three 8-byte pieces into (block, lane, half) of an image
+__device__ __forceinline__ void nd_b9_store4_at(bf16x8* blockp, int lane, int half, float v0, float v1, float v2, float v3) {
+    bf16x4 p1, p2, p3;
+    __bf16 a, b, c;
+    nd_b9_split(v0, a, b, c); p1[0] = a; p2[0] = b; p3[0] = c;
+    nd_b9_split(v1, a, b, c); p1[1] = a; p2[1] = b; p3[1] = c;
+    nd_b9_split(v2, a, b, c); p1[2] = a; p2[2] = b; p3[2] = c;
+    nd_b9_split(v3, a, b, c); p1[3] = a; p2[3] = b; p3[3] = c;
+    bf16x4* q = reinterpret_cast<bf16x4*>(blockp + lane) + half;
+    *(__attribute__((address_space(1))) bf16x4*)(q) = p1;
+    *(__attribute__((address_space(1))) bf16x4*)(q + 2 * 64) = p2;
+    *(__attribute__((address_space(1))) bf16x4*)(q + 4 * 64) = p3;
+}
+
 // the NP LDS-DMA pieces of one wave and K-step; bit pc of NTMASK: piece pc is requested with the nontemporal policy
 template <int PC, int NP, unsigned NTMASK>
 __device__ __forceinline__ void b9_stage_pieces(const bf16x8* const (&src)[NP], size_t step_units, bf16x8* slot, int first, int last) {
@@ -76,7 +110,10 @@ __device__ __forceinline__ void b9_stage_pieces(const bf16x8* const (&src)[NP], 
 // advanced by B9_BLOCK_UNITS per step; piece e = min(wave*NP + u, NPC-1) of a slot = (fragment e/3, plane e%3), fragments
 // 0 .. WN*FA-1 = the tile's w fragments, the rest its x fragments.  acc[i][j] += w fragment (wn*FA + i) x x fragment (wm*FB + j):
 // lane l of acc[i][j] holds D[n = 4*(l>>4) + r][m = l&15], i.e. 4 consecutive output columns n of activation row m.
-template <int FA, int FB, int WN, int WM, int NS, unsigned NTMASK = 0u>
+// SWAP: the operand roles of the MFMA exchanged (A = x fragment, B = w fragment): lane l of acc[i][j] then holds D[m = 4*(l>>4) + r][n = l&15],
+// i.e. 4 consecutive ACTIVATION rows m of output column n -- the form whose frag32b3 store is the TRANSPOSED image (k = m contiguous):
+// the V^T operand of the attention's P V contraction (nd_attention.hip, k_attention_b9).  Same products, same order of terms.
+template <int FA, int FB, int WN, int WM, int NS, unsigned NTMASK = 0u, bool SWAP = false>
 __device__ __forceinline__ void b9_mainloop_impl(f32x4 (&acc)[FA][FB], const bf16x8* (&src)[(((WN * FA + WM * FB) * 3) + WN * WM - 1) / (WN * WM)],
                                                  bf16x8* lds, int nk, int wave, int wn, int wm, int lane) {
     constexpr int NW = WN * WM, NFRAG = WN * FA + WM * FB, NPC = NFRAG * 3, NP = (NPC + NW - 1) / NW;
@@ -94,7 +131,8 @@ __device__ __forceinline__ void b9_mainloop_impl(f32x4 (&acc)[FA][FB], const bf1
     {                                                                                                                               \
         _Pragma("unroll") for (int i = 0; i < FA; ++i)                                                                              \
             _Pragma("unroll") for (int j = 0; j < FB; ++j)                                                                          \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[set][p][i], fx[set][q][j], acc[i][j], 0, 0, 0);              \
+                acc[i][j] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx[set][q][j], fw[set][p][i], acc[i][j], 0, 0, 0)        \
+                                 : __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[set][p][i], fx[set][q][j], acc[i][j], 0, 0, 0);       \
     }
     bf16x8 fw[2][3][FA], fx[2][3][FB];
     // prologue: steps 0 .. NS-1 -> slots 0 .. NS-1 (clamped past the end: valid data nobody reads), step 0 into register set 0
@@ -142,13 +180,14 @@ __device__ __forceinline__ void b9_mainloop_impl(f32x4 (&acc)[FA][FB], const bf1
 // NTW: the w pieces (fragments 0 .. WN*FA-1 of a slot) are requested nontemporally -- for launches whose w panels are read once while
 // their x panels are re-read by every column tile, so that the stream of w does not push x out of the Infinity Cache.  Which of a
 // wave's pieces are w pieces depends on the wave: the loop is instantiated per count of leading w pieces (wave-uniform switch).
-template <int FA, int FB, int WN, int WM, int NS, bool NTW = false>
+template <int FA, int FB, int WN, int WM, int NS, bool NTW = false, bool SWAP = false>
 __device__ __forceinline__ void b9_mainloop(f32x4 (&acc)[FA][FB], const bf16x8* (&src)[(((WN * FA + WM * FB) * 3) + WN * WM - 1) / (WN * WM)],
                                             bf16x8* lds, int nk, int wave, int wn, int wm, int lane) {
     constexpr int NW = WN * WM, NPC = (WN * FA + WM * FB) * 3, NP = (NPC + NW - 1) / NW;
     if constexpr (!NTW) {
-        b9_mainloop_impl<FA, FB, WN, WM, NS, 0u>(acc, src, lds, nk, wave, wn, wm, lane);
+        b9_mainloop_impl<FA, FB, WN, WM, NS, 0u, SWAP>(acc, src, lds, nk, wave, wn, wm, lane);
     } else {
+        static_assert(!SWAP, "the transposed-output form has no nontemporal variant");
         static_assert(NP <= 6, "one instantiation per count of w pieces");
         const int nw = min(max(WN * FA * 3 - wave * NP, 0), NP);
         switch (nw) {

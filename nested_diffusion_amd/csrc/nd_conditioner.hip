@@ -44,6 +44,7 @@ struct nd_cond_s {
     float *cols = nullptr, *tok = nullptr, *mid_tok = nullptr, *h = nullptr, *qkv = nullptr, *att = nullptr, *fc1 = nullptr;
     // ND_DTYPE_F32_SPLIT: frag32b3 images of the GEMM inputs (csrc/nd_b9.hpp): xs = the current [R, kpe | E] input, fc1s = GELU(fc1)
     void *xs = nullptr, *fc1s = nullptr;
+    void* qkv_img = nullptr;          // ND_DTYPE_F32_SPLIT: the attention's operand images (nd_gemm_split_qkv), where the shape supports them
     float* m[3] = {nullptr, nullptr, nullptr};       // the mapping MLPs' hidden activations: n_mlps slices of m_stride[l] floats each
     size_t m_stride[3] = {0, 0, 0};
     void *gemm_ws = nullptr, *lin_ws = nullptr;
@@ -96,6 +97,7 @@ static void carve(nd_cond_s* c, char* base, size_t* total) {
         c->fc1 = nullptr;
         c->xs = take(nd_split_bytes((int)R, (int)(kpe > E ? kpe : E)));
         c->fc1s = take(nd_split_bytes((int)R, (int)Hd));
+        c->qkv_img = take(nd_qkv_images_bytes((int)B, (int)N, g.num_heads));
     } else {
         c->fc1 = (float*)take(R * Hd * 4);
         c->xs = c->fc1s = nullptr;
@@ -238,8 +240,14 @@ static int vit_block(nd_cond_s* c, int block, const float* tin, float* tout, int
         // the same block with the four Linear layers on the bf16 matrix pipe, exact fp32 products (csrc/nd_b9.hpp): the weights are
         // frag32b3 images, every GEMM input is written as one by its producer (LayerNorm, attention and the fc1 epilogue)
         ND_TRY(nd_layernorm_split(tin, w.norm1_w, w.norm1_b, c->xs, R, E, g.ln_eps, st));
-        ND_TRY(nd_gemm_split(c->xs, w.qkv_w, w.qkv_b, nullptr, c->qkv, nullptr, R, E, 3 * E, ND_ACT_NONE, c->gemm_ws, c->gemm_ws_bytes, st));
-        ND_TRY(nd_attention_split(c->qkv, c->xs, B, N, g.num_heads, 64, st));
+        if (nd_qkv_images_supported(N, g.num_heads) && !getenv("ND_ATT_F32")) {
+            // attention on the bf16 matrix pipe too: the qkv Linear writes q, k and v^T as the MFMA operand images of the attention kernel
+            ND_TRY(nd_gemm_split_qkv(c->xs, w.qkv_w, w.qkv_b, c->qkv_img, B, N, g.num_heads, E, st));
+            ND_TRY(nd_attention_images(c->qkv_img, c->xs, 1, B, N, g.num_heads, st));
+        } else {        // N % 4 != 0 (the full forward's 197 tokens) or ND_ATT_F32=1: fp32 qkv, f32-input-MFMA attention (rounds 1-4)
+            ND_TRY(nd_gemm_split(c->xs, w.qkv_w, w.qkv_b, nullptr, c->qkv, nullptr, R, E, 3 * E, ND_ACT_NONE, c->gemm_ws, c->gemm_ws_bytes, st));
+            ND_TRY(nd_attention_split(c->qkv, c->xs, B, N, g.num_heads, 64, st));
+        }
         ND_TRY(nd_gemm_split(c->xs, w.proj_w, w.proj_b, tin, c->mid_tok, nullptr, R, E, E, ND_ACT_NONE, c->gemm_ws, c->gemm_ws_bytes, st));
         ND_TRY(nd_layernorm_split(c->mid_tok, w.norm2_w, w.norm2_b, c->xs, R, E, g.ln_eps, st));
         ND_TRY(nd_gemm_split(c->xs, w.fc1_w, w.fc1_b, nullptr, nullptr, c->fc1s, R, E, Hd, ND_ACT_GELU, c->gemm_ws, c->gemm_ws_bytes, st));

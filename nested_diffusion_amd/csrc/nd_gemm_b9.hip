@@ -32,7 +32,35 @@ struct B9Epilogue {
     float* out;             // [M][N] fp32 row-major or null
     bf16x8* out_split;      // frag32b3 image of [M][N] (N % 32 == 0) or null
     int act;
+    bf16x8* att;            // ATT form (the qkv Linear, N = 3 * heads * 64): the per-(image, head) qkv images of nd_b9.hpp, nothing else stored
+    B9AttLayout al;
 };
+
+// ATT form, q / k columns: the lane's 4 consecutive output columns n0 .. n0+3 (= 4 consecutive d of one head) of token row m
+__device__ __forceinline__ void b9_epilogue_att_qk(const B9Epilogue& e, f32x4 a, int m, int n0, int M) {
+    if (m >= M) return;
+    const int E = e.al.heads * 64;
+    const int which = n0 >= E ? 1 : 0, c = n0 - which * E, hd = c >> 6, d = c & 63;
+    const int b = m / e.al.ntok, tok = m - b * e.al.ntok;
+    float v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = a[r] + (e.bias ? e.bias[n0 + r] : 0.f);
+    bf16x8* blk = e.att + (size_t)(b * e.al.heads + hd) * e.al.units()
+                  + (size_t)((which ? e.al.k_block0() : e.al.q_block0()) + (tok >> 4) * 2 + (d >> 5)) * B9_BLOCK_UNITS;
+    nd_b9_store4_at(blk, (tok & 15) + 16 * ((d & 31) >> 3), (d & 7) >> 2, v[0], v[1], v[2], v[3]);
+}
+
+// ATT form, v columns (accumulators of the SWAP main loop): the lane's 4 consecutive token rows m0 .. m0+3 (ntok % 4 == 0: one image,
+// 4 consecutive keys) of output column n -> the permuted V^T block of nd_b9.hpp
+__device__ __forceinline__ void b9_epilogue_att_v(const B9Epilogue& e, f32x4 a, int m0, int n, int M) {
+    if (m0 >= M) return;
+    const int E = e.al.heads * 64;
+    const int c = n - 2 * E, hd = c >> 6, d = c & 63;
+    const int b = m0 / e.al.ntok, key = m0 - b * e.al.ntok, w = key & 31;
+    const float bn = e.bias ? e.bias[n] : 0.f;
+    bf16x8* blk = e.att + (size_t)(b * e.al.heads + hd) * e.al.units() + (size_t)(e.al.v_block0() + (d >> 4) * e.al.nkb() + (key >> 5)) * B9_BLOCK_UNITS;
+    nd_b9_store4_at(blk, (d & 15) + 16 * ((w & 15) >> 2), w >> 4, a[0] + bn, a[1] + bn, a[2] + bn, a[3] + bn);
+}
 
 // lane's 4 consecutive output columns n0 .. n0+3 of row m
 __device__ __forceinline__ void b9_epilogue(const B9Epilogue& e, f32x4 a, int m, int n0, int M, int N) {
@@ -60,7 +88,10 @@ __device__ __forceinline__ void b9_epilogue(const B9Epilogue& e, f32x4 a, int m,
 // split == -1: the workgroups past n_full each take HALF of a remainder tile along its x rows (FB / 2 row fragments per wave, the whole
 // K): a last round of half-length workgroups and no partial sums -- the tail form of the two-per-CU shape, whose tiles (K = 768) are
 // short against a fixup launch.  split >= 1: k-slabs as described above.
-template <int FA, int FB, int WN, int WM, int NS>
+// ATT: the qkv Linear of a ViT block with its output written as the attention's operand images (nd_b9.hpp): the tiles of the v
+// columns (n >= 2 * heads * 64; a tile never straddles the boundary: heads * 64 % (WN * FA * 16) == 0, checked on the host) run the main
+// loop with the MFMA operand roles exchanged, so that a lane holds 4 consecutive keys of one d -- 8-byte pieces of the V^T image.
+template <int FA, int FB, int WN, int WM, int NS, bool ATT = false>
 __global__ __launch_bounds__(64 * WN * WM) void k_gemm_b9(const bf16x8* __restrict__ xs, const bf16x8* __restrict__ ws, B9Epilogue ep, int M, int K,
                                                           int N, int n_full, int split, f32x4* __restrict__ part) {
     constexpr int NW = WN * WM, NPC = (WN * FA + WM * FB) * 3, NP = (NPC + NW - 1) / NW;
@@ -89,6 +120,24 @@ __global__ __launch_bounds__(64 * WN * WM) void k_gemm_b9(const bf16x8* __restri
             for (int i = 0; i < FA; ++i)
 #pragma unroll
                 for (int jj = 0; jj < HB; ++jj) acc[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (ATT) {
+                if (tn * WN * FA * 16 >= 2 * ep.al.heads * 64) {
+                    b9_mainloop<FA, HB, WN, WM, NS, false, true>(acc, src, lds, nkb, wave, wn, wm, lane);
+#pragma unroll
+                    for (int i = 0; i < FA; ++i)
+#pragma unroll
+                        for (int jj = 0; jj < HB; ++jj)
+                            b9_epilogue_att_v(ep, acc[i][jj], (mf0 + wm * HB + jj) * 16 + 4 * (lane >> 4), ((tn * WN + wn) * FA + i) * 16 + (lane & 15), M);
+                } else {
+                    b9_mainloop<FA, HB, WN, WM, NS>(acc, src, lds, nkb, wave, wn, wm, lane);
+#pragma unroll
+                    for (int i = 0; i < FA; ++i)
+#pragma unroll
+                        for (int jj = 0; jj < HB; ++jj)
+                            b9_epilogue_att_qk(ep, acc[i][jj], (mf0 + wm * HB + jj) * 16 + (lane & 15), ((tn * WN + wn) * FA + i) * 16 + 4 * (lane >> 4), M);
+                }
+                return;
+            }
             b9_mainloop<FA, HB, WN, WM, NS>(acc, src, lds, nkb, wave, wn, wm, lane);
 #pragma unroll
             for (int i = 0; i < FA; ++i)
@@ -125,6 +174,24 @@ __global__ __launch_bounds__(64 * WN * WM) void k_gemm_b9(const bf16x8* __restri
     for (int i = 0; i < FA; ++i)
 #pragma unroll
         for (int j = 0; j < FB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (ATT) {      // whole tiles only (the host launches no k-slabs in this form)
+        if (tn * WN * FA * 16 >= 2 * ep.al.heads * 64) {
+            b9_mainloop<FA, FB, WN, WM, NS, false, true>(acc, src, lds, c1 - c0, wave, wn, wm, lane);
+#pragma unroll
+            for (int i = 0; i < FA; ++i)
+#pragma unroll
+                for (int j = 0; j < FB; ++j)
+                    b9_epilogue_att_v(ep, acc[i][j], ((tm * WM + wm) * FB + j) * 16 + 4 * (lane >> 4), ((tn * WN + wn) * FA + i) * 16 + (lane & 15), M);
+        } else {
+            b9_mainloop<FA, FB, WN, WM, NS>(acc, src, lds, c1 - c0, wave, wn, wm, lane);
+#pragma unroll
+            for (int i = 0; i < FA; ++i)
+#pragma unroll
+                for (int j = 0; j < FB; ++j)
+                    b9_epilogue_att_qk(ep, acc[i][j], ((tm * WM + wm) * FB + j) * 16 + (lane & 15), ((tn * WN + wn) * FA + i) * 16 + 4 * (lane >> 4), M);
+        }
+        return;
+    }
     b9_mainloop<FA, FB, WN, WM, NS>(acc, src, lds, c1 - c0, wave, wn, wm, lane);
     if (slab >= 0) {     // raw accumulators of a k-slab: [remainder tile][slab][wave][fragment][lane], one coalesced 1 KiB store per fragment
         f32x4* pt = part + (((size_t)rem_index * split + slab) * NW + wave) * (FA * FB) * 64 + lane;
@@ -289,7 +356,7 @@ extern "C" int nd_gemm_split(const void* x_split, const void* w_split, const flo
         // no (or too small / misaligned) workspace: every tile whole -- same results up to summation order, longer tail
         p.n_full = p.tiles; p.rem = 0; p.split = 1;
     }
-    B9Epilogue ep{bias, res, out, (bf16x8*)out_split, act};
+    B9Epilogue ep{bias, res, out, (bf16x8*)out_split, act, nullptr, B9AttLayout{0, 0}};
     const unsigned grid = (unsigned)(p.n_full + p.rem * (p.split < 0 ? 2 : p.split));
     if (p.wide) {
         auto kern = k_gemm_b9<B9_FA, B9_FB, 2, 4, B9_NS>;
@@ -306,6 +373,38 @@ extern "C" int nd_gemm_split(const void* x_split, const void* w_split, const flo
         HIP_CHECK(hipGetLastError());
         if (p.rem > 0 && p.split > 1) hipLaunchKernelGGL((k_b9_fixup<B9_FA, B9_FB, 2, 2>), dim3(p.rem * 4 * B9_FA * B9_FB / 4), dim3(256), 0, st, (const f32x4*)workspace, ep, M, N, p.n_full, p.split);
     }
+    HIP_CHECK(hipGetLastError());
+    return ND_OK;
+}
+
+// ---- the qkv Linear of a ViT block with the attention's operand images as its output -------------------------------------------------
+extern "C" size_t nd_qkv_images_bytes(int B, int ntok, int heads) {
+    if (B < 1 || ntok < 1 || heads < 1) return 0;
+    return (size_t)B * heads * B9AttLayout{ntok, heads}.units() * 16;
+}
+
+// shapes the image form supports: whole 4-token runs per image (the V^T stores), q / k / v column ranges on tile boundaries
+extern "C" int nd_qkv_images_supported(int ntok, int heads) { return ntok >= 4 && (ntok % 4) == 0 && ntok <= 256 && heads >= 1 && ((heads * 64) % (2 * B9_FA * 16)) == 0; }
+
+extern "C" int nd_gemm_split_qkv(const void* x_split, const void* w_split, const float* bias, void* qkv_images, int B, int ntok, int heads, int K,
+                                 void* stream) {
+    if (!x_split || !w_split || !qkv_images) return nd_set_err(ND_ERR_ARG, "NULL tensor");
+    if (B < 1 || K < 32 || (K % 32)) return nd_set_err(ND_ERR_ARG, "need B >= 1 and K a positive multiple of 32 (K=%d)", K);
+    if (!nd_qkv_images_supported(ntok, heads))
+        return nd_set_err(ND_ERR_ARG, "qkv images need ntok %% 4 == 0, ntok <= 256 and heads * 64 a multiple of %d (ntok=%d, heads=%d)", 2 * B9_FA * 16, ntok, heads);
+    if (((uintptr_t)x_split | (uintptr_t)w_split | (uintptr_t)qkv_images) & 15) return nd_set_err(ND_ERR_ARG, "tensors must be 16-byte aligned");
+    const int M = B * ntok, N = 3 * heads * 64;
+    // the two-per-CU shape at every depth, whole tiles or half tiles only (no k-slabs: the fixup kernel has no image form)
+    const int BM = 2 * B9_FB * 16, BN = 2 * B9_FA * 16, ncu = nd_num_cus();
+    const int tiles = ((M + BM - 1) / BM) * (N / BN), slots = 2 * ncu, rem = tiles % slots;
+    int n_full = tiles, nrem = 0, split = 1;
+    if (rem > 0 && tiles > slots && 2 * rem <= ncu) { split = -1; nrem = rem; n_full = tiles - rem; }
+    const size_t lds_bytes = (size_t)B9_NS * (2 * B9_FA + 2 * B9_FB) * 3 * 1024;
+    B9Epilogue ep{bias, nullptr, nullptr, nullptr, ND_ACT_NONE, (bf16x8*)qkv_images, B9AttLayout{ntok, heads}};
+    auto kern = k_gemm_b9<B9_FA, B9_FB, 2, 2, B9_NS, true>;
+    HIP_CHECK(nd_allow_dynamic_lds((const void*)kern, lds_bytes));
+    hipLaunchKernelGGL(kern, dim3((unsigned)(n_full + nrem * (split < 0 ? 2 : 1))), dim3(256), lds_bytes, (hipStream_t)stream, (const bf16x8*)x_split,
+                       (const bf16x8*)w_split, ep, M, K, N, n_full, split, (f32x4*)nullptr);
     HIP_CHECK(hipGetLastError());
     return ND_OK;
 }

@@ -423,6 +423,8 @@ extern "C" int nd_layernorm_split(const float* x, const float* gamma, const floa
 #define AT_MAXF 16  // up to 256 keys
 // RING form (the default fp32 kernel): nd_attention.hip, a translation unit of its own (accumulators kept in VGPRs).
 hipError_t nd_launch_attention_ring(const float* qkv, float* out, int B, int N, int heads, int split_out, hipStream_t st);
+hipError_t nd_launch_attention_b9(const void* att, float* out, int B, int N, int heads, int split_out, hipStream_t st);      // nd_attention.hip
+extern "C" int nd_qkv_images_supported(int ntok, int heads);                                                                   // nd_gemm_b9.hip
 
 // fp16-operand form (the fp16 mode; not a mode of the reference): q, k, v are rounded to fp16 as they are staged, both
 // contractions run on v_mfma_f32_16x16x32_f16 with fp32 accumulation, the softmax is fp32 and the normalised probabilities
@@ -580,6 +582,17 @@ extern "C" int nd_attention(const float* qkv, float* out, int B, int N, int head
 // the fp32 attention with its result written as the frag32b3 image of [B*N, heads*64]: the input of the proj nd_gemm_split
 extern "C" int nd_attention_split(const float* qkv, void* out_split, int B, int N, int heads, int d, void* stream) {
     return attention_any(qkv, (float*)out_split, B, N, heads, d, ND_DTYPE_F32, 1, stream);
+}
+
+// The attention core on the bf16 matrix pipe with exact fp32 products (k_attention_b9): operands = the qkv images nd_gemm_split_qkv wrote.
+// out_dev: fp32 [B*N, heads*64] (out_is_split == 0) or the frag32b3 image of that matrix (the input of the proj nd_gemm_split).
+extern "C" int nd_attention_images(const void* qkv_images, void* out, int out_is_split, int B, int N, int heads, void* stream) {
+    if (!qkv_images || !out) return nd_set_err(ND_ERR_ARG, "NULL tensor");
+    if (B < 1 || heads < 1 || N < 1) return nd_set_err(ND_ERR_ARG, "bad B / N / heads");
+    if (!nd_qkv_images_supported(N, heads)) return nd_set_err(ND_ERR_ARG, "qkv images need N %% 4 == 0, N <= 256, heads * 64 %% 128 == 0 (N=%d, heads=%d)", N, heads);
+    if (((uintptr_t)qkv_images | (uintptr_t)out) & 15) return nd_set_err(ND_ERR_ARG, "tensors must be 16-byte aligned");
+    HIP_CHECK(nd_launch_attention_b9(qkv_images, (float*)out, B, N, heads, out_is_split ? 1 : 0, (hipStream_t)stream));
+    return ND_OK;
 }
 
 // ---------------------------------------------------------------------------------------------

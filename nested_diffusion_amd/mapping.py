@@ -102,8 +102,13 @@ class VisionTransformer:
         p, pre = self.p, f"blocks.{i}."
         N = tok.shape[0] // B
         h = ops.layernorm(tok, p[pre + "norm1.weight"], p[pre + "norm1.bias"], LN_EPS)
-        qkv = ops.gemm_bias_act(h, p[pre + "attn.qkv.weight"], p[pre + "attn.qkv.bias"])
-        a = ops.attention(qkv, B, N, self.num_heads, self.dtype)
+        if self.split and ops.qkv_images_supported(N, self.num_heads) and not os.environ.get("ND_ATT_F32"):
+            # attention on the bf16 matrix pipe as well: the qkv Linear writes the attention kernel's operand images (nd_vit_block's sequence)
+            img = ops.gemm_split_qkv(ops.split_rows(h), p[pre + "attn.qkv.weight"], p[pre + "attn.qkv.bias"], B, N, self.num_heads)
+            a = ops.attention_images(img, B, N, self.num_heads)
+        else:
+            qkv = ops.gemm_bias_act(h, p[pre + "attn.qkv.weight"], p[pre + "attn.qkv.bias"])
+            a = ops.attention(qkv, B, N, self.num_heads, self.dtype)
         tok = ops.gemm_bias_act(a, p[pre + "attn.proj.weight"], p[pre + "attn.proj.bias"], residual=tok)
         h = ops.layernorm(tok, p[pre + "norm2.weight"], p[pre + "norm2.bias"], LN_EPS)
         h = ops.gemm_bias_act(h, p[pre + "mlp.fc1.weight"], p[pre + "mlp.fc1.bias"], act="gelu")

@@ -209,6 +209,31 @@ def attention_split(qkv: torch.Tensor, B: int, N: int, heads: int) -> SplitMatri
     return out
 
 
+def qkv_images_supported(N: int, heads: int) -> bool:
+    return bool(_lib.load().nd_qkv_images_supported(int(N), int(heads)))
+
+
+def gemm_split_qkv(x: SplitMatrix, weight: SplitMatrix, bias: Optional[torch.Tensor], B: int, N: int, heads: int) -> torch.Tensor:
+    """The qkv Linear of a ViT block (x: image of [B*N, K], weight: image of [3*heads*64, K]) with its result written as the attention's
+    operand images (per image and head: q, k as frag32b3 blocks, v transposed; csrc/nd_b9.hpp).  Returns the opaque image buffer."""
+    lib = _lib.load()
+    if x.rows != B * N or weight.rows != 3 * heads * 64 or weight.K != x.K:
+        raise ValueError(f"x is {x.shape}, weight {weight.shape}: expected [{B * N}, K] and [{3 * heads * 64}, K]")
+    img = torch.empty(lib.nd_qkv_images_bytes(B, N, heads), dtype=torch.uint8, device=x.device)
+    check(lib.nd_gemm_split_qkv(ptr(x.data), ptr(weight.data), ptr(_f32(bias, "bias")) if bias is not None else None, ptr(img), B, N, heads, x.K,
+                                _stream(x.data)), "nd_gemm_split_qkv")
+    return img
+
+
+def attention_images(img: torch.Tensor, B: int, N: int, heads: int, want_split: bool = False):
+    """softmax(q k^T / 8) v on the bf16 matrix pipe with exact fp32 products, from the images gemm_split_qkv wrote: fp32 [B*N, heads*64], or
+    (want_split) its frag32b3 image for the proj gemm_split."""
+    out = SplitMatrix(B * N, heads * 64, img.device) if want_split else torch.empty(B * N, heads * 64, dtype=torch.float32, device=img.device)
+    check(_lib.load().nd_attention_images(ptr(img), ptr(out.data if want_split else out), 1 if want_split else 0, B, N, heads, _stream(img)),
+          "nd_attention_images")
+    return out
+
+
 def patchify_split(img: torch.Tensor, p: int) -> SplitMatrix:
     """im2col written as the frag32b3 image of [B*(H/p)*(W/p), Cin*p*p] (the input of the patch-embedding gemm_split)."""
     img = _f32(img, "img")

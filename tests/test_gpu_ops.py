@@ -215,6 +215,59 @@ def test_attention(B, N, heads):
     _close(out, ref, 1e-5)
 
 
+@pytest.mark.parametrize("B,N,heads", [(2, 196, 12), (3, 16, 2), (1, 4, 2), (2, 100, 2), (1, 256, 4), (2, 36, 2), (5, 132, 2), (1, 64, 2), (32, 196, 12)])
+def test_attention_on_the_bf16_pipe_from_qkv_images(B, N, heads):
+    """timm Attention.forward (call sites classification_train_separately.py:339-340) with BOTH contractions on the bf16 matrix pipe, exact
+    fp32 products: the qkv Linear writes the attention's operand images (q, k as frag32b3 blocks per head, v transposed with the keys of
+    a 32-block in score-accumulator order; nd_gemm_split_qkv), k_attention_b9 consumes them.  Against torch in fp64 on the same fp32
+    inputs (qkv Linear included), at the tolerance of the f32-input-MFMA kernel's test; against that kernel on the fp32 qkv; the split
+    output is the exact image of the fp32 output.  N = 4 / 16 / 36: one partial fragment, one workgroup per head; 100 / 132 / 196:
+    ragged last fragment and a half-empty last key block (never-written image rows behind it are poisoned with NaNs first);
+    256: the largest N; B = 32 x 196 x 12: the conditioner's own shape."""
+    from nested_diffusion_amd import _lib, ops
+    E = heads * 64
+    g = torch.Generator().manual_seed(N + B)
+    x = torch.randn(B * N, E, generator=g)
+    w = torch.randn(3 * E, E, generator=g) / E ** 0.5
+    b = torch.randn(3 * E, generator=g) * 0.1
+    assert ops.qkv_images_supported(N, heads)
+    xs, ws = ops.split_rows(x.cuda()), ops.split_rows(w.cuda())
+    # poison the buffer the images will land in: rows / keys past N are never written and must not reach the result
+    nbytes = _lib.load().nd_qkv_images_bytes(B, N, heads)
+    junk = torch.full((nbytes // 4,), float("nan"), device="cuda")
+    del junk
+    img = ops.gemm_split_qkv(xs, ws, b.cuda(), B, N, heads)
+    out = ops.attention_images(img, B, N, heads)
+    qkv64 = x.double() @ w.double().T + b.double()
+    t = qkv64.reshape(B, N, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    a = ((t[0] @ t[1].transpose(-2, -1)) * 0.125).softmax(-1)
+    ref = (a @ t[2]).transpose(1, 2).reshape(B * N, E)
+    _close(out, ref.float(), 1e-5)
+    assert torch.isfinite(out).all()
+    # the f32-input-MFMA kernel on the fp32 qkv of the same GEMM: the same arithmetic in another summation order
+    qkv32 = ops.gemm_split(xs, ws, b.cuda())
+    old = ops.attention(qkv32, B, N, heads)
+    _close(out, old.cpu(), 1e-5)
+    assert torch.equal(ops.join_rows(ops.attention_images(img, B, N, heads, want_split=True)), out)
+    assert torch.equal(ops.attention_images(img, B, N, heads), out)                       # reproducible
+
+
+def test_qkv_images_argument_checks():
+    from nested_diffusion_amd import _lib, ops
+    lib = _lib.load()
+    assert lib.nd_qkv_images_supported(196, 12) == 1 and lib.nd_qkv_images_supported(197, 12) == 0        # the full forward's cls token
+    assert lib.nd_qkv_images_supported(196, 1) == 0 and lib.nd_qkv_images_supported(260, 2) == 0
+    assert lib.nd_qkv_images_bytes(32, 196, 12) == 32 * 12 * (4 * 13 + 4 * 7) * 3072
+    x = ops.split_rows(torch.randn(2 * 197, 128).cuda())
+    w = ops.split_rows(torch.randn(384, 128).cuda())
+    buf = torch.empty(1 << 20, dtype=torch.uint8, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    assert lib.nd_gemm_split_qkv(_lib.ptr(x.data), _lib.ptr(w.data), None, _lib.ptr(buf), 2, 197, 2, 128, st) != 0
+    assert b"qkv images" in lib.nd_last_error()
+    assert lib.nd_attention_images(_lib.ptr(buf), _lib.ptr(buf), 0, 2, 197, 2, st) != 0
+    assert lib.nd_attention_images(None, _lib.ptr(buf), 0, 2, 196, 2, st) != 0
+
+
 def test_patchify_matches_conv2d():
     from nested_diffusion_amd import ops
     g = torch.Generator().manual_seed(0)
