@@ -14,7 +14,11 @@
  *  - `stream` is a hipStream_t passed as void* (NULL = default stream).
  *  - every function returns 0 on success, <0 on error; nd_last_error() gives the message.
  *    No C++ exception crosses the ABI.
- *  - fp32 storage and arithmetic throughout (f32-input MFMA, exact f32 products/accumulate).
+ *  - fp32 at the ABI: every tensor handed in or out is fp32 row-major (int64 votes aside) unless a declaration says "image".
+ *    INSIDE, operands live in MFMA lane order: frag16 (fp32, the weight-streaming layers), frag32b3 (three exact bf16 pieces per
+ *    fp32 value: every MFMA-bound layer -- the ViT Linear layers and attention, the ConditionalLinear blocks above 128 rows -- runs on
+ *    the bf16 matrix pipe with EXACT fp32 products and fp32 accumulation; csrc/nd_b9.hpp), frag32h (fp16, the fp16-operand mode).
+ *    The arithmetic is the reference's fp32 arithmetic in another summation order in every default mode.
  *  - one handle per GPU per process; not thread-safe for concurrent calls on one handle.
  */
 #ifndef NESTED_DIFFUSION_H

@@ -33,17 +33,6 @@ __device__ __forceinline__ void nd_lds_dma16(const float* sbase, unsigned voff_b
                  : "=&s"(saved_m0) : "v"(voff_bytes), "s"(sbase), "s"(lds_byte_addr) : "memory");
 }
 
-// exp(x) for x <= 0 (softmax arguments), ~1 ulp: exp2 of the product x*log2(e) carried in two pieces (t rounded + its exact
-// residual + the low part of log2 e), first-order correction on the result.  v_exp_f32 is the only transcendental; no range
-// handling is needed below zero (underflow flushes to 0, as the softmax wants).  x must be finite.
-__device__ __forceinline__ float nd_exp_neg(float x) {
-    const float L2E = 1.44269504088896340736f, L2E_LO = 1.92596299e-8f, LN2 = 0.69314718055994530942f;
-    const float t = x * L2E;
-    const float r = __builtin_fmaf(x, L2E, -t) + x * L2E_LO;
-    const float p = __builtin_amdgcn_exp2f(t);
-    return __builtin_fmaf(p, r * LN2, p);
-}
-
 #ifdef ND_ATT_STAMPS
 __device__ long long* nd_att_stamps = nullptr;     // tools/att_stamps.py (debug build only): 16 clocks per wave
 extern "C" int nd_debug_set_att_stamps(void* p) { return hipMemcpyToSymbol(HIP_SYMBOL(nd_att_stamps), &p, sizeof p) == hipSuccess ? 0 : -1; }

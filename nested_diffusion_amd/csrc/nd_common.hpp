@@ -45,11 +45,46 @@ __device__ __forceinline__ float nd_softplus(float x) {
     return x > 20.0f ? x : r;
 }
 
+// exp(x) for x <= 0 (softmax arguments), ~1 ulp: exp2 of the product x*log2(e) carried in two pieces (t rounded + its exact
+// residual + the low part of log2 e), first-order correction on the result.  v_exp_f32 is the only transcendental; no range
+// handling is needed below zero (underflow flushes to 0, as the softmax wants).  x must be finite.
+__device__ __forceinline__ float nd_exp_neg(float x) {
+    const float L2E = 1.44269504088896340736f, L2E_LO = 1.92596299e-8f, LN2 = 0.69314718055994530942f;
+    const float t = x * L2E;
+    const float r = __builtin_fmaf(x, L2E, -t) + x * L2E_LO;
+    const float p = __builtin_amdgcn_exp2f(t);
+    return __builtin_fmaf(p, r * LN2, p);
+}
+
+// erf(a) to < 1 ulp of the exact value (measured against fp64 over [-6, 6] with a correctly rounded exp: 0.97 ulp; the device exp above adds
+// at most 1 ulp of exp(r) <= 0.4 to the tail branch), branch-free: both of N. Juffa's minimax forms (|a| <= 0.9277: a + a P(a^2); beyond:
+// 1 - exp(Q(|a|))) are evaluated and one is selected -- 15 FMAs and one v_exp_f32 per value, where the library erff takes a data-dependent
+// branch per lane group.  Used by the exact-erf GELU of timm's Mlp (the fc1 epilogue: 19 M values per ViT block at B = 32).
+__device__ __forceinline__ float nd_erf(float a) {
+    const float t = fabsf(a), s = a * a;
+    float r = __builtin_fmaf(-1.72853470e-5f, t, 3.83197126e-4f);
+    const float u = __builtin_fmaf(-3.88396438e-3f, t, 2.42546219e-2f);
+    r = __builtin_fmaf(r, s, u);
+    r = __builtin_fmaf(r, t, -1.06777877e-1f);
+    r = __builtin_fmaf(r, t, -6.34846687e-1f);
+    r = __builtin_fmaf(r, t, -1.28717512e-1f);
+    r = __builtin_fmaf(r, t, -t);
+    const float big = __builtin_copysignf(1.0f - nd_exp_neg(fmaxf(r, -100.0f)), a);      // (the clamp keeps the argument finite for huge |a|)
+    float q = -5.96761703e-4f;
+    q = __builtin_fmaf(q, s, 4.99119423e-3f);
+    q = __builtin_fmaf(q, s, -2.67681349e-2f);
+    q = __builtin_fmaf(q, s, 1.12819925e-1f);
+    q = __builtin_fmaf(q, s, -3.76125336e-1f);
+    q = __builtin_fmaf(q, s, 1.28379166e-1f);
+    const float small = __builtin_fmaf(q, a, a);
+    return t > 0.927734375f ? big : small;
+}
+
 __device__ __forceinline__ float nd_act(float v, int act) {
     switch (act) {
         case ND_ACT_SOFTPLUS: return nd_softplus(v);
         case ND_ACT_RELU: return v > 0.0f ? v : 0.0f;
-        case ND_ACT_GELU: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+        case ND_ACT_GELU: return 0.5f * v * (1.0f + nd_erf(v * 0.70710678118654752440f));
         default: return v;
     }
 }
@@ -454,7 +489,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_skinny(SkinnyInline di, const Sk
         switch (eact) {
             case ND_ACT_SOFTPLUS: activate([](float v) { return nd_softplus(v); }); break;
             case ND_ACT_RELU: activate([](float v) { return v > 0.0f ? v : 0.0f; }); break;
-            case ND_ACT_GELU: activate([](float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }); break;
+            case ND_ACT_GELU: activate([](float v) { return 0.5f * v * (1.0f + nd_erf(v * 0.70710678118654752440f)); }); break;
             default: break;
         }
 #pragma unroll

@@ -420,3 +420,21 @@ def test_linear_four_and_five_row_fragments_with_up_to_six_weight_fragments(dtyp
             ref = F.softplus((xr @ wr.T).float() + b)
             err = (out.cpu().double() - ref.double()).abs().max().item()
             assert err <= 2e-5 * max(1.0, ref.abs().max().item()), (M, K, N, err)
+
+
+def test_gelu_exact_erf_accuracy_through_an_identity_gemm():
+    """timm's Mlp uses the exact-erf GELU (fc1 epilogue).  nd_erf is a branch-free < 1 ulp erf (csrc/nd_common.hpp); a GEMM against the
+    identity (exact products, exact sums) exposes it element by element: against torch in fp64 the error stays within fp32 rounding of
+    the three steps (argument product, erf, 1 + erf) -- absolute 2e-7 max(1, |v|) -- over [-9, 9], denormal-small and large arguments."""
+    from nested_diffusion_amd import ops
+    K = 64
+    g = torch.Generator().manual_seed(1)
+    x = torch.cat([torch.linspace(-9, 9, 4096 * K).reshape(4096, K), torch.randn(2048, K, generator=g) * 1.5,
+                   torch.tensor([[0.0, -0.0, 1e-30, -1e-30, 0.927734375 * 2 ** 0.5, -0.927734375 * 2 ** 0.5, 30.0, -30.0, 1e4, -1e4] + [0.5] * (K - 10)])])
+    eye = torch.eye(K)
+    for out in (ops.gemm_bias_act(x.cuda(), eye.cuda(), None, act="gelu"),                       # f32-input MFMA kernel's epilogue
+                ops.gemm_split(x.cuda(), ops.split_rows(eye.cuda()), None, act="gelu")):        # bf16-pipe kernel's epilogue (fc1)
+        ref = torch.nn.functional.gelu(x.double())
+        err = (out.cpu().double() - ref).abs()
+        assert torch.isfinite(out).all()
+        assert bool((err <= 2e-7 * x.double().abs().clamp(min=1.0)).all()), float(err.max())

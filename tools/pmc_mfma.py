@@ -23,7 +23,7 @@ for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursiv
             key = k.split("(")[0].replace("void ", "").strip()
             if key.startswith("_Z9k_gemm_b9"):       # rocprofv3 leaves this one mangled: template arguments FA, FB, WN, WM, NS
                 import re
-                key = "k_gemm_b9<" + ", ".join(re.findall(r"Li(\d+)E", key)[:5]) + ">"
+                key = "k_gemm_b9<" + ", ".join(re.findall(r"Li(\d+)E", key)[:5]) + (", att" if "Lb1E" in key else "") + ">"    # att: the qkv Linear writing attention images
             acc[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
 failed = []
 fp = os.path.join(root, "failed_passes.txt")

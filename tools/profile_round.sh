@@ -1,11 +1,11 @@
 #!/bin/bash
-# Round profile artefacts (run on the GPU box):  R=r04 bash tools/profile_round.sh [bench|stats|pmc ...]   (default: all three)
+# Round profile artefacts (run on the GPU box):  R=r05 bash tools/profile_round.sh [bench|stats|pmc ...]   (default: all three)
 #   bench  bench lines (headline + secondary shapes)
 #   stats  rocprofv3 kernel-trace stats of bench.py (headline, K = 1, f16, mc = 20)
 #   pmc    HBM-traffic PMC passes (FETCH_SIZE and WRITE_SIZE in SEPARATE runs, kernel-trace only) over the sampler-only bench at every
 #          shape bench.py reports a roofline for -> traffic.json keyed by shape
 # Output under gpurun_out/prof_$R/; copy the summaries into profiles/ (tools/pmc_traffic.py writes traffic.json there directly).
-R=${R:-r04}
+R=${R:-r05}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$R
 WHAT=${@:-bench stats pmc}
 mkdir -p $OUT
