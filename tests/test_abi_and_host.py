@@ -366,3 +366,15 @@ def test_conditioner_and_batch_abi_argument_validation_without_gpu():
     assert lib.nd_predict_batch(None, None, None, None, None, 1, 1, 1, 0.5, 1, None) != 0
     assert lib.nd_seed(None, 1, 0) != 0
     assert lib.nd_resident_weight_bytes(None, 0) == -1
+
+
+def test_documents_quote_what_the_committed_profiles_say():
+    """tools/check_docs.py: every tagged figure of profiles/README.md and DESIGN.md equals the value in the CSV / log / JSON it names; the
+    stage table of DESIGN 7b and the first section of profiles/README.md cite the newest round's kernel stats; the header's convention
+    block describes the operand storage the library uses (round 4's verdict found all three drifted)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_docs.py")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert "0 problem(s)" in r.stdout
