@@ -26,6 +26,10 @@ int nd_set_err(int code, const char* fmt, ...);
             return nd_set_err(ND_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
     } while (0)
 
+#ifndef B9_DIRECT_STORE
+#define B9_DIRECT_STORE 0          // 1 (variant builds): fp32 outputs stored straight from the accumulators (rounds 4 - early 5)
+#endif
+
 struct B9Epilogue {
     const float* bias;      // [N] or null
     const float* res;       // [M][N] or null (added after the activation)
@@ -62,10 +66,8 @@ __device__ __forceinline__ void b9_epilogue_att_v(const B9Epilogue& e, f32x4 a, 
     nd_b9_store4_at(blk, (d & 15) + 16 * ((w & 15) >> 2), w >> 4, a[0] + bn, a[1] + bn, a[2] + bn, a[3] + bn);
 }
 
-// lane's 4 consecutive output columns n0 .. n0+3 of row m
-__device__ __forceinline__ void b9_epilogue(const B9Epilogue& e, f32x4 a, int m, int n0, int M, int N) {
-    if (m >= M || n0 >= N) return;
-    float v[4];
+// bias, activation, residual of the lane's 4 consecutive output columns n0 .. n0+3 of row m (m < M, n0 < N)
+__device__ __forceinline__ void b9_epilogue_values(const B9Epilogue& e, f32x4 a, int m, int n0, int N, float (&v)[4]) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int nn = min(n0 + r, N - 1);
@@ -74,6 +76,13 @@ __device__ __forceinline__ void b9_epilogue(const B9Epilogue& e, f32x4 a, int m,
         if (e.res && n0 + r < N) t += e.res[(size_t)m * N + n0 + r];
         v[r] = t;
     }
+}
+
+// lane's 4 consecutive output columns n0 .. n0+3 of row m
+__device__ __forceinline__ void b9_epilogue(const B9Epilogue& e, f32x4 a, int m, int n0, int M, int N) {
+    if (m >= M || n0 >= N) return;
+    float v[4];
+    b9_epilogue_values(e, a, m, n0, N, v);
     if (e.out) {
         float* p = e.out + (size_t)m * N + n0;
         if (n0 + 3 < N && (N & 3) == 0) *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
@@ -199,6 +208,36 @@ __global__ __launch_bounds__(64 * WN * WM) void k_gemm_b9(const bf16x8* __restri
         for (int i = 0; i < FA; ++i)
 #pragma unroll
             for (int j = 0; j < FB; ++j) *(__attribute__((address_space(1))) f32x4*)(pt + (i * FB + j) * 64) = acc[i][j];
+        return;
+    }
+    // fp32 row-major output of an interior tile: through LDS, so that the global stores are whole 512-byte row segments.  In the MFMA
+    // accumulator a lane holds 4 columns of ONE row and 16 lanes hold 16 different rows: a direct store instruction touches 16 rows x 64 B
+    // (half cache lines), which costs 6-12 us per ViT launch against the frag32b3 store's contiguous pieces
+    // (tools/bench_gemm_store_pattern.py, profiles/r05_gemm_store_pattern.txt).  The operand ring is free here; row stride 144 floats puts
+    // both the fragment-order writes and the row-order reads on every bank exactly four times (no conflicts).
+    constexpr int BNc = WN * FA * 16, BMc = WM * FB * 16, SLD = BNc + 16;
+    if (ep.out && !ep.out_split && (tm + 1) * BMc <= M && (tn + 1) * BNc <= N && (N & 3) == 0 && (size_t)NS * NPC * 1024 >= (size_t)BMc * SLD * 4 &&
+        !B9_DIRECT_STORE) {
+        float* stage = reinterpret_cast<float*>(lds);
+        __builtin_amdgcn_s_barrier();            // every wave's LDS-DMA has landed (vmcnt(0) above) and nobody reads operands any more
+#pragma unroll
+        for (int i = 0; i < FA; ++i)
+#pragma unroll
+            for (int j = 0; j < FB; ++j) {
+                const int ml = (wm * FB + j) * 16 + (lane & 15), nl = (wn * FA + i) * 16 + 4 * (lane >> 4);
+                float v[4];
+                b9_epilogue_values(ep, acc[i][j], tm * BMc + ml, tn * BNc + nl, N, v);
+                *reinterpret_cast<f32x4*>(stage + ml * SLD + nl) = f32x4{v[0], v[1], v[2], v[3]};
+            }
+        __syncthreads();
+        constexpr int LPR = BNc / 4, RPP = (64 * NW) / LPR;          // lanes per row, rows per pass of the whole workgroup
+        const int rr = tid / LPR, cc = (tid - rr * LPR) * 4;
+        float* ob = ep.out + (size_t)(tm * BMc) * N + (size_t)tn * BNc + cc;
+#pragma unroll
+        for (int p0 = 0; p0 < BMc; p0 += RPP) {
+            const f32x4 q = *reinterpret_cast<const f32x4*>(stage + (p0 + rr) * SLD + cc);
+            *(__attribute__((address_space(1))) f32x4*)(ob + (size_t)(p0 + rr) * N) = q;
+        }
         return;
     }
 #pragma unroll

@@ -73,6 +73,26 @@ def test_config3_two_ranks_at_config_dims_equal_one_process(tmp_path):
     assert a["accuracy"] == b["accuracy"]
 
 
+def test_config3_four_real_ranks_at_config_dims_equal_one_process(tmp_path):
+    """Half of configs[3]'s group as REAL processes: four ranks x 32 rows (global batch 128) at config dims, each rank a process of its own
+    with its own HIP context, handles and hipGraphs, meeting in the batch's single all-gather -- against one process holding all 128 rows.
+    (A GPU box admits six processes on its card: four ranks is the largest even split that fits beside the test runner; with >= 4 GPUs the
+    ranks take one device each and gather over RCCL.)  Same criterion as the two-rank run."""
+    torch.cuda.empty_cache()
+    backend = "nccl" if torch.cuda.device_count() >= 4 else "gloo"
+    one, four = str(tmp_path / "w1.pt"), str(tmp_path / "w4.pt")
+    _run_ranks(1, one, backend, extra=("--global-batch", "128"))
+    _run_ranks(4, four, backend, extra=("--global-batch", "128"))
+    a, b = torch.load(one), torch.load(four)
+    assert a["world"] == 1 and b["world"] == 4 and b["backend"] == backend
+    assert a["rows_per_rank"] == 128 and b["rows_per_rank"] == 32
+    assert a["prob"].shape == b["prob"].shape == (128, 2)
+    err = float((a["prob"] - b["prob"]).abs().max())
+    print(f"configs[3] per-rank workload, 4 real ranks x 32 vs 1 x 128 at config dims ({backend}): max |class-prob delta| = {err:.2e}")
+    assert err <= 2e-6, err
+    assert a["accuracy"] == b["accuracy"]
+
+
 def test_config3_real_shape_8_shards_of_32_equal_one_process_of_256(tmp_path):
     """configs[3] at its REAL shape -- batch 256 as 8 ranks x 32 rows at config dims -- against one process holding all 256 rows.
     The two sides cross kernel families: a 32-row shard streams through k_skinny, the 256-row batch goes through the LDS-tiled
