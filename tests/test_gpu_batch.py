@@ -216,6 +216,43 @@ def test_mapping_mlp_tails_share_launches(dtype, B, K, monkeypatch):
             assert (shared[k].cpu() - ref[k]).abs().max() < 2e-5 * max(1.0, float(ref[k].abs().max())), k
 
 
+@pytest.mark.parametrize("heads,embed", [(2, 128), (3, 192)])
+def test_conditioner_attention_forms_agree(heads, embed, monkeypatch):
+    """The ViT blocks' attention core on the bf16 matrix pipe (qkv images + k_attention_b9: the default where N % 4 == 0 and the head
+    count is even) against the f32-input-MFMA kernel on the fp32 qkv (ND_ATT_F32=1; also what a ViT with an odd head count gets, here 3
+    heads of 64: the image form does not apply and the conditioner falls back by itself): the same guiding predictions to fp32 rounding,
+    both within the oracle's tolerance, and the C-level call equals the operator-by-operator launches bitwise in either form."""
+    from nested_diffusion_amd import ops
+    from nested_diffusion_amd.mapping import Classifier, GuidingConditioner, VisionTransformer
+    depth, img = 3, 32
+    vp, mlps = _vit_and_mlps(embed=embed, heads=heads, depth=depth, img=img, K=3, widths=(64, 32, 32))
+    x = torch.rand(5, 3, img, img, generator=torch.Generator().manual_seed(18)).cuda()
+    ref = ref_cpu.compute_guiding_prediction(vp, mlps, x.cpu(), heads, depth, full_vit=False, share_prefix=True)
+    assert ops.qkv_images_supported(4, heads) == (heads % 2 == 0)
+    outs = {}
+    for form in ("b9", "f32"):
+        if form == "f32":
+            monkeypatch.setenv("ND_ATT_F32", "1")
+        vit = VisionTransformer(vp, heads)
+        assert vit.split
+        cond = GuidingConditioner(vit, [Classifier(m) for m in mlps])
+        got = cond.compute_guiding_prediction(x, include_full_vit=False)
+        monkeypatch.setenv("ND_MLP_TAIL_PER_MEMBER", "1")
+        for a, b in zip(cond.compute_guiding_prediction(x, include_full_vit=False), cond.compute_guiding_prediction_py(x, include_full_vit=False)):
+            assert torch.equal(a, b), form
+        monkeypatch.delenv("ND_MLP_TAIL_PER_MEMBER")
+        for k in range(3):
+            assert (got[k].cpu() - ref[k]).abs().max() < 2e-5 * max(1.0, float(ref[k].abs().max())), (form, k)
+        outs[form] = got
+    monkeypatch.delenv("ND_ATT_F32")
+    for a, b in zip(outs["b9"], outs["f32"]):
+        assert (a - b).abs().max().item() < 2e-5 * max(1.0, float(b.abs().max()))
+        if heads % 2 == 0:
+            assert not torch.equal(a, b)                      # two kernels, two summation orders
+        else:
+            assert torch.equal(a, b)                          # odd head count: both runs took the f32-input-MFMA attention
+
+
 def test_conditioner_driven_through_ctypes_only():
     """What a C caller of include/nested_diffusion.h does, spelled out with ctypes and raw device pointers: no
     nested_diffusion_amd.mapping / ops orchestration anywhere -- pack the MLP weights, create the conditioner, hand over the
