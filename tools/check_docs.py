@@ -57,7 +57,59 @@ def check_tag(args: dict) -> str:
     return f"unknown tag {args}"
 
 
+def actual_value(args: dict):
+    """(field name in the tag, value in the file) of a tag, for --fix"""
+    if "csv" in args:
+        rows = [r for r in csv.DictReader(open(os.path.join(PROF, args["csv"]))) if args["name"] in r["Name"]]
+        if len(rows) != 1:
+            return None
+        return ("avg_us", float(rows[0]["AverageNs"]) / 1e3) if "avg_us" in args else ("calls", int(rows[0]["Calls"]))
+    if "log" in args:
+        m = re.search(r"(\d+) passed", open(os.path.join(PROF, args["log"])).read())
+        return ("passed", int(m.group(1))) if m else None
+    if "json" in args:
+        txt = [l for l in open(os.path.join(PROF, args["json"])).read().splitlines() if l.strip().startswith("{")][-1]
+        v = json.loads(txt)
+        for k in args["key"].split("."):
+            v = v[k]
+        return ("value", float(v) * float(args.get("scale", "1")))
+    return None
+
+
+def fix() -> int:
+    """--fix: rewrite every tagged figure (the number right in front of its tag, and the tag's own copy) from the file the tag names, at
+    the digits the tag shows.  For re-profiled rounds: the prose around the figures is the author's business, the figures are the files'."""
+    n = 0
+    for doc in ("profiles/README.md", "DESIGN.md"):
+        path = os.path.join(ROOT, doc)
+        text = open(path).read()
+
+        def sub(m):
+            nonlocal n
+            args = {k: (q if q is not None and v.startswith('"') else v) for k, v, q in KV.findall(m.group(2))}
+            try:
+                got = actual_value(args)
+            except Exception:
+                got = None
+            if got is None:
+                return m.group(0)
+            field, val = got
+            new = f"{val:.{_digits(args[field])}f}" if not isinstance(val, int) else str(val)
+            if new != args[field]:
+                n += 1
+            tag = re.sub(rf"\b{field}={re.escape(args[field])}", f"{field}={new}", m.group(2))
+            return f"{new}<!--chk {tag}-->"
+
+        text2 = re.sub(r"([0-9][0-9.]*)<!--chk\s+(.*?)-->", sub, text)
+        if text2 != text:
+            open(path, "w").write(text2)
+    print(f"check_docs --fix: {n} figure(s) rewritten")
+    return 0
+
+
 def main() -> int:
+    if "--fix" in sys.argv[1:]:
+        return fix()
     problems, n_tags = [], 0
     for doc in ("profiles/README.md", "DESIGN.md"):
         text = open(os.path.join(ROOT, doc)).read()
