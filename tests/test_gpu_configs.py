@@ -69,7 +69,7 @@ def test_config3_two_ranks_at_config_dims_equal_one_process(tmp_path):
     print(f"configs[3] per-rank workload, 2 ranks x 32 vs 1 x 64 at config dims ({backend}): max |class-prob delta| = {err:.2e}")
     assert a["prob"].shape == b["prob"].shape == (64, 2)
     # the 64-row and the 32-row launches deal the k-chunks to the waves differently: fp32 summation order only
-    assert err <= 2e-6, err
+    assert err <= 1e-5, err
     assert a["accuracy"] == b["accuracy"]
 
 
@@ -89,7 +89,9 @@ def test_config3_four_real_ranks_at_config_dims_equal_one_process(tmp_path):
     assert a["prob"].shape == b["prob"].shape == (128, 2)
     err = float((a["prob"] - b["prob"]).abs().max())
     print(f"configs[3] per-rank workload, 4 real ranks x 32 vs 1 x 128 at config dims ({backend}): max |class-prob delta| = {err:.2e}")
-    assert err <= 2e-6, err
+    # shard and full batch pick different launch geometries in the streaming layers (row passes, k-chunk dealing): fp32 summation order
+    # only, carried through 100 reverse steps -- measured 1.7e-6; the criterion is 1e-3
+    assert err <= 1e-5, err
     assert a["accuracy"] == b["accuracy"]
 
 
@@ -113,9 +115,12 @@ def test_config3_real_shape_8_shards_of_32_equal_one_process_of_256(tmp_path):
            f"max |class-prob delta| = {err:.2e}, accuracy {b['accuracy']:.4f} vs {a['accuracy']:.4f}")
     print(msg)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", "r4_config3_real_shape.log"), "w") as f:
+    with open(os.path.join(ROOT, "gpurun_out", "r5_config3_real_shape.log"), "w") as f:
         f.write(msg + "\n")
-    assert err <= 2e-6, err
+    # the two sides differ in EVERY streaming layer's launch form (32-row shards: k_skinny step blocks, mapping-MLP tails in shared
+    # launches; 256 rows: LDS-tiled step blocks on the bf16 pipe, per-member LDS-tiled MLP layers): summation orders only, carried through
+    # 100 reverse steps.  Measured 1.9e-6 (round 4) / 3.6e-6 (round 5: more layers differ); the criterion is 1e-3.
+    assert err <= 1e-5, err
     assert a["accuracy"] == b["accuracy"]
 
 
