@@ -201,6 +201,12 @@ __device__ __forceinline__ float nd_ldg(const float* p) {
 //   MODE 1: that value is not stored; its projection onto C rows is: part[m,c,tile] = sum_{n in tile} pw[c,n]*v
 //           -- lin3 + unetnorm3 + softplus + lin4 (latent_model.py:181-184) in one pass.
 //   MODE 2: split-K partial sums, no epilogue: part[slab, m, n] = sum_{k in slab} x[m,k] w[n,k]
+#ifndef ND_PF_TWO
+#define ND_PF_TWO 0
+#endif
+#ifndef ND_PF_LEAD
+#define ND_PF_LEAD 0            // register stages between the cross-launch prefetch and the end of a wave's stream (~0.45 us each at M = 32)
+#endif
 struct SkinnyDesc {
     const float* x;      // frag16 [M][K]   (frag32h in the fp16 kernels: opaque 1 KiB blocks either way)
     const float* w;      // frag16 [N][K]   (nn.Linear weight, rows padded to 16 with zeros)
@@ -211,6 +217,9 @@ struct SkinnyDesc {
     float* part;         // MODE 1: [M, C, ceil(N/16)];  MODE 2: [S, Mpad, Npad]
     int K, N, C, act, out_packed;
     int keep;            // 1: this member's W is read with default-policy loads in an NT kernel (kept in the Infinity Cache across steps)
+    const float* pf;     // or null: the weight matrix (same shape, same packing) of the NEXT launch of this member's step chain: near the end
+                         // of its stream every wave touches the lines of the first register stage the same workgroup of that launch will ask
+                         // for -- same blockIdx, hence same XCD and L2 -- so that launch's ramp starts on L2 hits instead of HBM latency
 };
 
 // Up to ND_INLINE_DESCS members' descriptors travel BY VALUE in the kernel arguments (table == nullptr): a workgroup then has its
@@ -305,6 +314,17 @@ __global__ __launch_bounds__(WAVES * 64) void k_skinny(SkinnyInline di, const Sk
         }
     }
 
+    // cross-launch prefetch (d.pf): lane L of instruction q touches line (q*64 + L) % 8 of chunk (q*64 + L) / 8 of this wave's first
+    // group in the next launch -- chunk ci = (fragment ci / U, chunk wave*U + ci % U of that fragment's row), 8 lines of 128 B each
+    const float* pfp[2] = {nullptr, nullptr};
+    if (MODE != 2 && NT && d.pf) {      // NT: the launch streams more than the Infinity Cache keeps (small launches run out of it: K = 1 measured 1.3 % slower with the prefetch)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int idx = q * 64 + lane, ci = min(idx >> 3, nact * U - 1), f = ci / U, u = ci - f * U;
+            pfp[q] = d.pf + ((size_t)min(fi0 + f, nfr - 1) * nch + min(wave * U + u, nch - 1)) * 256 + (idx & 7) * 32;
+        }
+    }
+    float pfv = 0.f;
     const int nck = max(c1 - c0, 0);
     const int ngroups = nck / U;     // full groups of U chunks
     const int ngw = ngroups > wave ? (ngroups - wave + WAVES - 1) / WAVES : 0;
@@ -360,7 +380,12 @@ __global__ __launch_bounds__(WAVES * 64) void k_skinny(SkinnyInline di, const Sk
             __builtin_amdgcn_sched_group_barrier(0x008, MR, 0);                                      \
         }                                                                                            \
         __builtin_amdgcn_sched_barrier(0);
+        const int pf_at = ngw > ND_PF_LEAD ? (ngw - ND_PF_LEAD) & ~1 : 0;        // ~ND_PF_LEAD register stages before the end of the stream
         for (; i + 1 < ngw; i += 2) {
+            if (MODE != 2 && pfp[0] && i == pf_at && ND_PF_LEAD > 0) {
+                pfv += nd_ldg(pfp[0]) + nd_ldg(pfp[1]);
+                if (ND_PF_TWO) pfv += nd_ldg(pfp[0] + (size_t)WAVES * U * 256) + nd_ldg(pfp[1] + (size_t)WAVES * U * 256);     // the wave's second group too
+            }
             LD(wB, xB, G(i + 1));
             MMA(wA, xA);
             ND_MIX()
@@ -369,6 +394,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_skinny(SkinnyInline di, const Sk
             ND_MIX()
         }
 #undef ND_MIX
+        if (ND_PF_LEAD == 0 && MODE != 2 && pfp[0]) pfv += nd_ldg(pfp[0]) + nd_ldg(pfp[1]);      // (variant: behind the last stage's loads)
         if (i < ngw) MMA(wA, xA);
     };
     const bool nt_here = NT && !d.keep;
@@ -400,6 +426,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_skinny(SkinnyInline di, const Sk
 #ifdef ND_WG_TIMING
     const long long dbg_t1 = wall_clock64();
 #endif
+    if (ND_PF_LEAD < 0 && MODE != 2 && pfp[0]) {                                  // (variant: at the start of the epilogue)
+        pfv += nd_ldg(pfp[0]) + nd_ldg(pfp[1]);
+        if (ND_PF_TWO) pfv += nd_ldg(pfp[0] + (size_t)WAVES * U * 256) + nd_ldg(pfp[1] + (size_t)WAVES * U * 256);
+    }
     // park the epilogue operands (in registers since the prologue) in LDS; the first barrier below publishes them
     if (MODE != 2) {
         if (tid < NF * 16) { ssc[tid >> 4][tid & 15] = r_sc; ssh[tid >> 4][tid & 15] = r_sh; }
@@ -551,6 +581,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_skinny(SkinnyInline di, const Sk
             }
         }
     }
+    // the prefetched values themselves are of no interest: a never-true use keeps the loads (and the compiler's own count of them) alive
+    if (MODE != 2 && pfv == 1.2345678e30f && d.part) d.part[0] = pfv;
 #ifdef ND_WG_TIMING
     if (tid == 0 && nd_dbg_times) {
         long long* q = nd_dbg_times + ((size_t)MODE * 8192 + blockIdx.x) * 3;      // one region per MODE: the last launch of each stays

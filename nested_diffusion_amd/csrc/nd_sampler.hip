@@ -737,6 +737,9 @@ extern "C" int nd_load_member(nd_handle h, int k, const nd_member_weights* w, vo
     ds[L_ENC2] = SkinnyDesc{m.e1, m.w_enc6, m.sc2, m.sh2, m.xe, nullptr, nullptr, H, F, C, ND_ACT_NONE, 1};
     ds[L_LIN2] = SkinnyDesc{m.h1, m.w_lin2, m.A[1], m.Cc[1], m.h2, nullptr, nullptr, F, F, C, ND_ACT_SOFTPLUS, opk};
     ds[L_LIN3] = SkinnyDesc{m.h2, m.w_lin3, m.A[2], m.Cc[2], nullptr, m.w_lin4, m.epart, F, F, C, ND_ACT_SOFTPLUS, 0};
+    // each block's stream ends by touching the first lines of the next launch's stream (SkinnyDesc::pf): lin2 -> lin3 of the same step,
+    // lin3 -> lin2 of the next one.  ND_NO_XPREFETCH=1: off (the A/B switch).
+    if (!getenv("ND_NO_XPREFETCH")) { ds[L_LIN2].pf = m.w_lin3; ds[L_LIN3].pf = m.w_lin2; }
     ds[L_LIN2S] = ds[L_LIN2]; ds[L_LIN3S] = ds[L_LIN3];
     if (h->b9) {   // the same two blocks on frag32b3 operands: h1s -> lin2 -> h2s (out_packed 3) -> lin3 + lin4 -> eps partials
         ds[L_LIN2S].x = (const float*)m.h1s; ds[L_LIN2S].w = (const float*)m.w_lin2s; ds[L_LIN2S].out = (float*)m.h2s; ds[L_LIN2S].out_packed = 3;
