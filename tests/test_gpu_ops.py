@@ -215,7 +215,8 @@ def test_attention(B, N, heads):
     _close(out, ref, 1e-5)
 
 
-@pytest.mark.parametrize("B,N,heads", [(2, 196, 12), (3, 16, 2), (1, 4, 2), (2, 100, 2), (1, 256, 4), (2, 36, 2), (5, 132, 2), (1, 64, 2), (32, 196, 12)])
+@pytest.mark.parametrize("B,N,heads", [(2, 196, 12), (3, 16, 2), (1, 4, 2), (2, 100, 2), (1, 256, 4), (2, 36, 2), (5, 132, 2), (1, 64, 2), (32, 196, 12),
+                                       (10, 196, 12)])          # B = 10: 558 tiles on 512 slots -> the qkv GEMM's HALF-TILE tail writes images too
 def test_attention_on_the_bf16_pipe_from_qkv_images(B, N, heads):
     """timm Attention.forward (call sites classification_train_separately.py:339-340) with BOTH contractions on the bf16 matrix pipe, exact
     fp32 products: the qkv Linear writes the attention's operand images (q, k as frag32b3 blocks per head, v transposed with the keys of
