@@ -392,11 +392,14 @@ __global__ __launch_bounds__(256, 2) void k_attention_b9(const bf16x8* __restric
                 if constexpr (!(ND_AB9_ABL & 4)) { AB9_S(2, 2) AB9_S(2, 1) AB9_S(1, 2) AB9_S(2, 0) AB9_S(0, 2) AB9_S(1, 1) AB9_S(1, 0) AB9_S(0, 1) AB9_S(0, 0) }
 #undef AB9_S
                 if (st + 1 < NST && !(ND_AB9_ABL & (4 | 16))) {
+                    // the next step's three operand reads EARLY in this step's MFMAs (after 1, 2 and 3 x NJ of them): dealt evenly they
+                    // put the last read right in front of the next step's lgkmcnt(0) and expose its latency once per step
 #pragma unroll
                     for (int k = 0; k < 3; ++k) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 3 * NJA, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, NJA, 0);
                         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                     }
+                    __builtin_amdgcn_sched_group_barrier(0x008, 6 * NJA, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -503,6 +506,14 @@ __global__ __launch_bounds__(256, 2) void k_attention_b9(const bf16x8* __restric
                     o[j][df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vr[(ND_AB9_ABL & 16) ? 0 : (st & 1)][pp], pr[j][qq], o[j][df], 0, 0, 0);
                 if constexpr (!(ND_AB9_ABL & 8)) { AB9_O(2, 2) AB9_O(2, 1) AB9_O(1, 2) AB9_O(2, 0) AB9_O(0, 2) AB9_O(1, 1) AB9_O(1, 0) AB9_O(0, 1) AB9_O(0, 0) }
 #undef AB9_O
+                if (st + 1 < NST && !(ND_AB9_ABL & (8 | 16))) {          // the next step's operand reads early in this step's MFMAs, as in the score steps
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, NJA, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, 6 * NJA, 0);
+                }
                 // pin the step's MFMAs HERE: they are pure register operations whose results are only stored at the very end, and instruction
                 // selection otherwise emits the whole P V chain behind the last barrier -- with every V^T operand of every tile held (spilled)
                 // until then.  An empty volatile asm that takes and returns the accumulators is ordered with the barriers.
