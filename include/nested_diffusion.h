@@ -159,6 +159,22 @@ int nd_profile_read(nd_handle h, float *out_us, int *n_samples);
  * intervals are stamped on every replay and are not left over from the eager first call. */
 int nd_profile_probe_nodes(nd_handle h);
 
+/* FORM OF THE SAMPLING LOOP (diffusion_utils.py:145-157, the T iterations of p_sample_loop).  mode 0: 3T+1 kernel nodes of a
+ * hipGraph (head, lin2 block, lin3 + lin4 block per step).  mode 1: ONE kernel launch for the whole loop where the shape allows
+ * (csrc/nd_persist.hip: 17..32 rows per member, fp32 operands, <= 8 members whose weights exceed the Infinity Cache; any other call
+ * keeps mode 0): each member's workgroups stay on their CUs for all T steps and meet at per-member barriers, members `skew_us`
+ * microseconds apart, so one member's reductions run under the others' weight streams.  Same bits as mode 0.  The one-launch form
+ * needs every workgroup of its grid resident at once, i.e. the device to itself while it runs (one process per GPU; processes that
+ * share a device select mode 0).  A handle starts in the mode ND_PERSIST names (default: see nd_create); skew_us < 0 keeps the
+ * current skew.  Drops the recorded graphs.
+ *   nd_loop_form      1 if the most recently recorded or enqueued loop took the one-launch form, else 0
+ *   nd_persist_status synchronises the device and returns 0 when no barrier wait of a one-launch loop has been abandoned since the
+ *                     last reset (1 otherwise: results of that call are invalid -- every spin is bounded, a wait of more than one
+ *                     second means the grid was not resident); reset != 0 clears the flag. */
+int nd_set_loop_form(nd_handle h, int mode, float skew_us);
+int nd_loop_form(nd_handle h);
+int nd_persist_status(nd_handle h, int reset);
+
 /* Copy of an internal per-member activation (tests / debugging), converted from the packed layout to
  * row-major: which = 0 xe [rows<=B, F], 1 h1 [rows<=M, F], 2 h2 [rows<=M, F] -> dst_dev [rows, F]. */
 int nd_member_buffer(nd_handle h, int member, int which, float *dst_dev, int rows, void *stream);
@@ -185,6 +201,9 @@ int nd_linear(const float *x_dev, const void *w_packed_dev, const float *scale_d
  * out6 = {grid.x, grid.y, grid.z (k-slabs), fragment slots per workgroup, k-chunks per slab, threads per workgroup}.
  * mode 0 fused activation, 1 lin3+lin4 projection, 2 split-K partial sums. */
 int nd_skinny_plan(int K, int N, int M, int n_members, int dtype, int mode, int *out6);
+/* Row fragments (16 rows each) a weight-streaming workgroup keeps per pass at M rows -- the kernel's MT template argument (1, 2, 4, or
+ * 5 where five save a whole pass over the weights: 65..80 rows, the reference's batch_size 70, configs/chest_x_ray.yml:66). < 0: error. */
+int nd_skinny_row_fragments(int M);
 
 /* Which kernel one ConditionalLinear block of the sampler (latent_model.py:178-184; K = N = feature_dim) runs at
  * M = B * mc_trials rows (mc_trials = 20 at classification_train_separately.py:770-771, batch_size 70 in

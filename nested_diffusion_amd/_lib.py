@@ -103,6 +103,9 @@ SIGNATURES = {
     "nd_p_sample": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _vp]),
     "nd_sample": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "nd_set_profiling": (_i, [_vp, _i]),
+    "nd_set_loop_form": (_i, [_vp, _i, C.c_float]),
+    "nd_loop_form": (_i, [_vp]),
+    "nd_persist_status": (_i, [_vp, _i]),
     "nd_profile_read": (_i, [_vp, C.POINTER(C.c_float), C.POINTER(_i)]),
     "nd_profile_probe_nodes": (_i, [_vp]),
     "nd_resident_weight_bytes": (C.c_longlong, [_vp, _i]),
@@ -127,6 +130,7 @@ SIGNATURES = {
     "nd_linear": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "nd_skinny_plan": (_i, [_i, _i, _i, _i, _i, _i, C.POINTER(_i)]),
     "nd_step_plan": (_i, [_i, _i, _i, _i, C.POINTER(_i)]),
+    "nd_skinny_row_fragments": (_i, [_i]),
     "nd_gemm_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "nd_gemm_bias_act": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "nd_split_bytes": (_sz, [_i, _i]),

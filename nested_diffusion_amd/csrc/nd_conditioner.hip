@@ -45,6 +45,7 @@ struct nd_cond_s {
     // ND_DTYPE_F32_SPLIT: frag32b3 images of the GEMM inputs (csrc/nd_b9.hpp): xs = the current [R, kpe | E] input, fc1s = GELU(fc1)
     void *xs = nullptr, *fc1s = nullptr;
     void* qkv_img = nullptr;          // ND_DTYPE_F32_SPLIT: the attention's operand images (nd_gemm_split_qkv), where the shape supports them
+    int qkv_img_tokens = 0;           // token count the image buffer is sized for (the prefix blocks' patch count), 0: none reserved
     float* m[3] = {nullptr, nullptr, nullptr};       // the mapping MLPs' hidden activations: n_mlps slices of m_stride[l] floats each
     size_t m_stride[3] = {0, 0, 0};
     void *gemm_ws = nullptr, *lin_ws = nullptr;
@@ -97,7 +98,11 @@ static void carve(nd_cond_s* c, char* base, size_t* total) {
         c->fc1 = nullptr;
         c->xs = take(nd_split_bytes((int)R, (int)(kpe > E ? kpe : E)));
         c->fc1s = take(nd_split_bytes((int)R, (int)Hd));
-        c->qkv_img = take(nd_qkv_images_bytes((int)B, (int)N, g.num_heads));
+        // the attention's operand images (92 MB at B = 32, 196 tokens, 12 heads) only where a block can use them: the prefix blocks run
+        // at the patch count `ntok`; a token count the image form does not take (the full forward's 197: N % 4 != 0) or ND_ATT_F32=1
+        // keeps the fp32 qkv buffer above and reserves nothing here
+        c->qkv_img_tokens = (nd_qkv_images_supported((int)ntok, g.num_heads) && !getenv("ND_ATT_F32")) ? (int)ntok : 0;
+        c->qkv_img = c->qkv_img_tokens ? take(nd_qkv_images_bytes((int)B, c->qkv_img_tokens, g.num_heads)) : nullptr;
     } else {
         c->fc1 = (float*)take(R * Hd * 4);
         c->xs = c->fc1s = nullptr;
@@ -240,7 +245,7 @@ static int vit_block(nd_cond_s* c, int block, const float* tin, float* tout, int
         // the same block with the four Linear layers on the bf16 matrix pipe, exact fp32 products (csrc/nd_b9.hpp): the weights are
         // frag32b3 images, every GEMM input is written as one by its producer (LayerNorm, attention and the fc1 epilogue)
         ND_TRY(nd_layernorm_split(tin, w.norm1_w, w.norm1_b, c->xs, R, E, g.ln_eps, st));
-        if (nd_qkv_images_supported(N, g.num_heads) && !getenv("ND_ATT_F32")) {
+        if (c->qkv_img && N <= c->qkv_img_tokens && nd_qkv_images_supported(N, g.num_heads) && !getenv("ND_ATT_F32")) {
             // attention on the bf16 matrix pipe too: the qkv Linear writes q, k and v^T as the MFMA operand images of the attention kernel
             ND_TRY(nd_gemm_split_qkv(c->xs, w.qkv_w, w.qkv_b, c->qkv_img, B, N, g.num_heads, E, st));
             ND_TRY(nd_attention_images(c->qkv_img, c->xs, 1, B, N, g.num_heads, st));

@@ -219,7 +219,11 @@ __global__ __launch_bounds__(64 * WN * WM) void k_gemm_b9(const bf16x8* __restri
     if (ep.out && !ep.out_split && (tm + 1) * BMc <= M && (tn + 1) * BNc <= N && (N & 3) == 0 && (size_t)NS * NPC * 1024 >= (size_t)BMc * SLD * 4 &&
         !B9_DIRECT_STORE) {
         float* stage = reinterpret_cast<float*>(lds);
-        __builtin_amdgcn_s_barrier();            // every wave's LDS-DMA has landed (vmcnt(0) above) and nobody reads operands any more
+        // The ring is reused as the staging buffer: every wave's LDS-DMA must have landed and every operand read must have returned
+        // before any wave writes here.  b9_mainloop ends on vmcnt(0), but this reuse must not depend on that: wait for both counters
+        // explicitly, then a full workgroup barrier with memory ordering (a bare s_barrier gives the compiler neither).
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __syncthreads();
 #pragma unroll
         for (int i = 0; i < FA; ++i)
 #pragma unroll

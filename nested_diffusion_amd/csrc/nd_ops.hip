@@ -172,6 +172,12 @@ extern "C" int nd_skinny_plan(int K, int N, int M, int n_members, int dtype, int
     return ND_OK;
 }
 
+// Row fragments (16 rows each) a k_skinny workgroup keeps per pass over the weights at M rows: nd_pick_mt, the kernel's MT.
+extern "C" int nd_skinny_row_fragments(int M) {
+    if (M < 1) return nd_set_err(ND_ERR_ARG, "M must be >= 1");
+    return nd_pick_mt(M);
+}
+
 // Which kernel a ConditionalLinear block of the sampler (K = N = F) runs at M = B*mc rows, and its tile plan.
 extern "C" int nd_step_plan(int F, int M, int n_members, int dtype, int* out8) {
     if (!out8) return nd_set_err(ND_ERR_ARG, "out8 is NULL");

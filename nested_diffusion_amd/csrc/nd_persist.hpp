@@ -1,0 +1,42 @@
+// nd_persist.hpp -- the ONE-LAUNCH form of a whole p_sample_loop (csrc/nd_persist.hip): interface between that translation unit and
+// the graph builder in csrc/nd_sampler.hip.  gfx950 only.
+//
+// Reference: diffusion/diffusion_utils.py:133-163 (the T-loop), diffusion/latent_model.py:173-184 (what one step evaluates).
+#pragma once
+#include "nd_common.hpp"
+#include "nd_step.hpp"
+
+// Barrier block in the handle's workspace: word g*32 = arrival counter of the launch's g-th member (each on a 128-byte line of its
+// own); the first ND_PERSIST_BAR_ZERO_BYTES are zeroed by a memset node in front of EVERY launch (epochs are counted within a launch);
+// word ND_INLINE_DESCS*32 = sticky error word (a barrier wait gave up), cleared only by nd_bind_workspace / nd_persist_status(reset).
+#define ND_PERSIST_BAR_WORDS ((ND_INLINE_DESCS + 1) * 32)
+#define ND_PERSIST_BAR_ZERO_BYTES (ND_INLINE_DESCS * 32 * 4)
+#define ND_PERSIST_ERR_WORD (ND_INLINE_DESCS * 32)
+
+struct PersistScalars {
+    unsigned* bar;
+    int nm, B, M, maxM, F, T;
+    int skew;          // start offset between consecutive members, in ticks of the 100 MHz wall clock (0: all start together)
+    int spin_ticks;    // a barrier wait longer than this sets the error word and the workgroup leaves the kernel
+    int active;        // members that run (experiments: ND_PERSIST_ACTIVE; the others' workgroups leave at once, their outputs are not written)
+};
+
+struct PersistArgs {                         // by value in the kernel arguments, read through the constant address space
+    SkinnyDesc l2[ND_INLINE_DESCS];          // lin2 block of each member (x = h1, out = h2, scale / shift = the [T, F] folds)
+    SkinnyDesc l3[ND_INLINE_DESCS];          // lin3 + lin4 block (x = h2, pw = lin4.weight, part = the partial-sum buffer)
+    MemberDev mem[ND_INLINE_DESCS];
+    StepIO io;
+    PersistScalars s;
+};
+
+struct PersistPlan {
+    bool ok;             // the shape runs as one launch (else: the per-step kernels)
+    void* fn;
+    dim3 grid, block;
+    unsigned lds;
+    hipError_t err;      // preparing the launch (dynamic-LDS attribute of the kernel on this device)
+    const char* why;     // when !ok
+};
+
+// M rows per member, nm members, C classes, F = feature width (K = N = F); half: fp16 operands.
+PersistPlan nd_persist_plan(int F, int M, int nm, int C, int half);

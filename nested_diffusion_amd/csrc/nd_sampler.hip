@@ -6,8 +6,10 @@
 //   diffusion/diffusion_utils.py:54-111    p_sample / p_sample_t_1to0
 //   diffusion/latent_model.py:93-105,169-184  ConditionalLinear / ConditionalModel.forward
 #include "nd_common.hpp"
+#include "nd_step.hpp"
 #include "nd_cond_gemm.hpp"
 #include "nd_b9.hpp"
+#include "nd_persist.hpp"
 #include "nd_rng.hpp"
 #include "../../include/nested_diffusion.h"
 
@@ -49,69 +51,6 @@ int nd_set_err(int code, const char* fmt, ...) {
             return nd_set_err(ND_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
     } while (0)
 
-// ---------------------------------------------------------------------------------------------
-// device-side member record (everything the head / final kernels need)
-// ---------------------------------------------------------------------------------------------
-struct MemberDev {
-    const float* lin1_w;   // [F, 2C] (workspace copy)
-    const float* lin4_b;   // [C]
-    const float* A1;       // [T, F] folded gain  (unetnorm1 scale * embed1[t])
-    const float* C1;       // [T, F] folded shift
-    const float* xe;       // frag16 [B, F]
-    float* h1;             // frag16 [M, F]
-    float* ybuf;           // [2, maxM, C]
-    const float* epart;    // [M, C, NT]
-    int h16;               // layout h1 is written in: 0 frag16 fp32, 1 frag32h fp16, 2 frag32b3 (three bf16 pieces per value, csrc/nd_b9.hpp:
-                           // the input of the lin2 block on the bf16 matrix pipe; h1 then points at that image)
-};
-
-#define ND_MAX_C 8
-struct MemberInline { MemberDev m[ND_INLINE_DESCS]; };   // by value in the kernel arguments (members == nullptr): see SkinnyInline
-
-// Pointers that come out of descriptor structs are generic to the compiler; loads through them become flat_load, which is
-// counted on vmcnt AND lgkmcnt and cannot be waited on selectively -- the step head's "tables in flight under the reduction"
-// would serialise at the first LDS access.  These casts put the accesses in the global address space.
-typedef const __attribute__((address_space(1))) float* nd_gcf;
-typedef __attribute__((address_space(1))) float* nd_gf;
-#define ND_GC(p) ((nd_gcf)(p))
-#define ND_GW(p) ((nd_gf)(p))
-
-struct StepIO {             // per-launch tensors with a member-major leading stride
-    const float* yhat;  size_t yhat_ms;    // [nm][B][C]
-    const float* ymean; size_t ymean_ms;   // [nm][B][C]
-    const float* noise; size_t noise_ms;   // [nm][T][M][C]
-    float* y0_out;      size_t y0_ms;      // [nm][M][C]
-    float* seq_out;     size_t seq_ms;     // [nm][T+1][M][C] or null
-    const float* y_in;  size_t yin_ms;     // [nm][M][C] (eps_theta entry point only)
-    const float* alphas; const float* omabs;
-};
-
-// diffusion_utils.py:68-92 in the reference's operation order, fp32, no FMA contraction, so the
-// posterior is bit-identical to the CPU path for identical eps.
-__device__ __forceinline__ float nd_posterior(float y, float ymean, float eps, float z, float alpha_t, float s_t,
-                                              float s_tm1) {
-#pragma clang fp contract(off)
-    const float st2 = s_t * s_t;
-    const float sab_t = sqrtf(1.0f - st2);
-    const float stm2 = s_tm1 * s_tm1;
-    const float sab_tm1 = sqrtf(1.0f - stm2);
-    const float sa = sqrtf(alpha_t);
-    const float g0 = (1.0f - alpha_t) * sab_tm1 / st2;
-    const float g1 = stm2 * sa / st2;
-    const float g2 = 1.0f + (sab_t - 1.0f) * (sa + sab_tm1) / st2;
-    const float y0r = 1.0f / sab_t * (y - (1.0f - sab_t) * ymean - eps * s_t);
-    const float mean = g0 * y0r + g1 * y + g2 * ymean;
-    const float bh = stm2 / st2 * (1.0f - alpha_t);
-    return mean + sqrtf(bh) * z;
-}
-
-// diffusion_utils.py:99-111
-__device__ __forceinline__ float nd_y0_reparam(float y, float ymean, float eps, float s_t) {
-#pragma clang fp contract(off)
-    const float sab_t = sqrtf(1.0f - s_t * s_t);
-    return 1.0f / sab_t * (y - (1.0f - sab_t) * ymean - eps * s_t);
-}
-
 // eps[m, c] = sum over the n-tiles of lin3's projected partials (lin4.bias added by the caller); fixed
 // reduction tree (thread-strided, wave shuffle, then waves in order) => reproducible.  All C classes
 // are reduced in one pass (C is a template parameter: everything stays in registers).
@@ -141,19 +80,6 @@ __device__ __forceinline__ void nd_reduce_eps(const float* __restrict__ epart, i
         for (int w = 0; w < NT_THREADS / 64; ++w) tot += red[w * C + c];
         out[c] = tot;
     }
-}
-
-// One element of h1 = softplus(A1[t] * (lin1.W [y_t, yhat]) + C1[t]) * xe (latent_model.py:173-177 after the folds of SURVEY 7.3):
-// a pinned sequence of FMAs, so the two step-head kernels return the same bits.  w: the 2C entries of lin1.weight's row.
-template <int C, typename WT>
-__device__ __forceinline__ float nd_head_element(const WT& w, const float (&yv)[C], const float (&yh)[C], float a, float cc, float xe) {
-#pragma clang fp contract(off)
-    float u = 0.f;
-#pragma unroll
-    for (int q = 0; q < C; ++q) u = __builtin_fmaf(w[q], yv[q], u);
-#pragma unroll
-    for (int q = 0; q < C; ++q) u = __builtin_fmaf(w[C + q], yh[q], u);
-    return nd_softplus(__builtin_fmaf(a, u, cc)) * xe;
 }
 
 #define ND_HEAD_INIT 0    // y = noise[0] + y_T_mean                       (diffusion_utils.py:139-140)
@@ -513,6 +439,10 @@ struct nd_handle_s {
     float* tile_ws = nullptr;              // k-slab accumulators of k_cond_gemm's split tail (large-M steps only)
     bool b9 = false;                       // the large-M step blocks run on the bf16 matrix pipe (frag32b3 copies of lin2 / lin3 exist)
     unsigned long long* rng_state = nullptr;   // {seed, batch counter | first image << 32} of the in-library noise (nd_seed)
+    unsigned* persist_bar = nullptr;           // barrier block of the one-launch loop (nd_persist.hpp): per-member arrival counters + sticky error word
+    int persist_mode = 0;                      // ND_PERSIST: 0 = per-step kernels (hipGraph form), 1 = one launch per p_sample_loop where nd_persist_plan allows
+    int persist_skew_ticks = 0;                // ND_PERSIST_SKEW_US: start offset between consecutive members (100 MHz ticks)
+    bool persist_last = false;                 // the most recently recorded / enqueued loop took the one-launch form
     float* noise_ws = nullptr;             // [K][T][max_rows][C] draws of the in-library noise (noise_dev == NULL)
     float* logits_ws = nullptr;            // [K][max_batch][C] guiding-prediction logits of nd_predict_batch
     int sched_T = 0;
@@ -558,6 +488,7 @@ static void carve(nd_handle_s* h, char* base, size_t* total) {
     h->alphas = cv.take<float>(T);
     h->omabs = cv.take<float>(T);
     h->rng_state = cv.take<unsigned long long>(2);
+    h->persist_bar = cv.take<unsigned>(ND_PERSIST_BAR_WORDS);
     h->noise_ws = cv.take<float>(K * T * mM * C);
     h->logits_ws = cv.take<float>(K * mB * C);
     h->xpack = cv.take<float>(pB * D);
@@ -623,6 +554,8 @@ extern "C" int nd_create(const nd_config* cfg, nd_handle* out) {
     nd_handle_s* h = new nd_handle_s();
     h->cfg = *cfg;
     h->members.resize(cfg->n_members);
+    if (const char* e = getenv("ND_PERSIST")) h->persist_mode = atoi(e);
+    if (const char* e = getenv("ND_PERSIST_SKEW_US")) h->persist_skew_ticks = (int)(atof(e) * 100.0);
     *out = h;
     return ND_OK;
 }
@@ -657,6 +590,7 @@ extern "C" int nd_bind_workspace(nd_handle h, void* ws, size_t bytes) {
     HIP_CHECK(hipMemset(h->xpack, 0, (size_t)((char*)h->members[0].sc0 - (char*)h->xpack)));
     for (auto& m : h->members) HIP_CHECK(hipMemset(m.e0, 0, (size_t)((char*)m.splitk - (char*)m.e0)));
     HIP_CHECK(hipMemset(h->rng_state, 0, 2 * sizeof(unsigned long long)));
+    HIP_CHECK(hipMemset(h->persist_bar, 0, ND_PERSIST_BAR_WORDS * sizeof(unsigned)));
     return ND_OK;
 }
 
@@ -873,6 +807,27 @@ extern "C" int nd_set_profiling(nd_handle h, int enable) {
     return ND_OK;
 }
 
+extern "C" int nd_set_loop_form(nd_handle h, int mode, float skew_us) {
+    if (!h) return nd_set_err(ND_ERR_ARG, "handle is NULL");
+    if (mode != 0 && mode != 1) return nd_set_err(ND_ERR_ARG, "mode must be 0 (per-step kernels) or 1 (one launch per loop)");
+    if (skew_us > 1e6f) return nd_set_err(ND_ERR_ARG, "skew_us out of range");
+    h->persist_mode = mode;
+    if (skew_us >= 0.f) h->persist_skew_ticks = (int)(skew_us * 100.0f);
+    drop_graphs(h);
+    return ND_OK;
+}
+
+extern "C" int nd_loop_form(nd_handle h) { return h && h->persist_last ? 1 : 0; }
+
+extern "C" int nd_persist_status(nd_handle h, int reset) {
+    if (!h || !h->ws) return nd_set_err(ND_ERR_STATE, "workspace not bound");
+    HIP_CHECK(hipDeviceSynchronize());
+    unsigned flag = 0;
+    HIP_CHECK(hipMemcpy(&flag, h->persist_bar + ND_PERSIST_ERR_WORD, sizeof flag, hipMemcpyDeviceToHost));
+    if (reset && flag) HIP_CHECK(hipMemset(h->persist_bar + ND_PERSIST_ERR_WORD, 0, sizeof flag));
+    return flag ? 1 : 0;
+}
+
 // event-record nodes of a graph about to be instantiated (-1 if the graph cannot be walked)
 static int count_event_record_nodes(hipGraph_t g) {
     size_t n = 0;
@@ -1020,6 +975,18 @@ struct Emitter {
             last = node;
         }
     }
+    void memset32(void* dst, size_t bytes) {           // zero `bytes` (a multiple of 4) at dst
+        if (err != hipSuccess) return;
+        if (!graph) {
+            err = hipMemsetAsync(dst, 0, bytes, st);     // eager, or recorded by the stream capture
+        } else {
+            hipMemsetParams p{};
+            p.dst = dst; p.elementSize = 4; p.width = bytes / 4; p.height = 1; p.pitch = bytes; p.value = 0;
+            hipGraphNode_t node;
+            err = hipGraphAddMemsetNode(&node, graph, last ? &last : nullptr, last ? 1 : 0, &p);
+            last = node;
+        }
+    }
     void emit(void* fn, dim3 grid, dim3 block, void** args, size_t lds = 0) {
         if (err != hipSuccess) return;
         if (!graph) {
@@ -1049,6 +1016,39 @@ static hipError_t emit_loop(nd_handle_s* h, Emitter& em, int m0, int nm, StepIO 
         mi.m[g] = h->members_host[m0 + g];
         i2.d[g] = h->descs_host[(size_t)L_LIN2 * K + m0 + g];
         i3.d[g] = h->descs_host[(size_t)L_LIN3 * K + m0 + g];
+    }
+    // ONE launch for the whole loop where the plan allows (csrc/nd_persist.hip): [zero the arrival counters] -> k_persist_loop
+    h->persist_last = false;
+    if (h->persist_mode && inl) {
+        const PersistPlan pp = nd_persist_plan(F, M, nm, C, h->half);
+        if (pp.ok) {
+            if (pp.err != hipSuccess) return pp.err;
+            PersistArgs pa{};
+            for (int g = 0; g < nm; ++g) { pa.l2[g] = i2.d[g]; pa.l3[g] = i3.d[g]; pa.mem[g] = mi.m[g]; }
+            pa.io = io;
+            const char* act = getenv("ND_PERSIST_ACTIVE");                  // experiments only: run the first n members of the launch
+            pa.s = PersistScalars{h->persist_bar, nm, B, M, maxM, F, T, h->persist_skew_ticks, 100000000 /* 1 s of the 100 MHz clock */,
+                                  act ? atoi(act) : nm};
+            note_h_layout(h, m0, nm, false);
+            hipEvent_t* ev = nullptr;
+            if (h->profiling) {
+                if (h->probe_events.size() < 4) {
+                    const size_t old = h->probe_events.size();
+                    h->probe_events.resize(4);
+                    for (size_t e = old; e < 4; ++e)
+                        if (hipEventCreate(&h->probe_events[e]) != hipSuccess) return hipErrorOutOfMemory;
+                }
+                ev = h->probe_events.data();
+            }
+            em.memset32(h->persist_bar, ND_PERSIST_BAR_ZERO_BYTES);
+            if (ev) em.record(ev[0]);
+            void* ap[] = {&pa};
+            em.emit(pp.fn, pp.grid, pp.block, ap, pp.lds);
+            if (ev) em.record(ev[1]);
+            h->probe_steps = 0;
+            h->persist_last = true;
+            return em.err;
+        }
     }
     SkinnyDesc d0{};
     const dim3 ghead((F + 1023) / 1024, M, nm);

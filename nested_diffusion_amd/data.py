@@ -9,17 +9,42 @@ import torch
 
 
 class SyntheticLoader:
-    def __init__(self, n_batches: int, batch_size: int, num_classes: int, seed: int = 1234, size: int = 224):
+    """shard = (lo, hi): yield only rows [lo, hi) of every global batch (a rank's slice; the generator still runs over the whole
+    batch, so row i holds the same pixels at any world size)."""
+
+    def __init__(self, n_batches: int, batch_size: int, num_classes: int, seed: int = 1234, size: int = 224, shard=None):
         self.n, self.B, self.C, self.seed, self.size = n_batches, batch_size, num_classes, seed, size
+        self.shard = tuple(shard) if shard is not None else None
+        self.global_batch = batch_size
 
     def __len__(self):
         return self.n
 
     def __iter__(self):
         g = torch.Generator().manual_seed(self.seed)
+        lo, hi = self.shard if self.shard is not None else (0, self.B)
         for _ in range(self.n):
-            yield (torch.rand(self.B, 3, self.size, self.size, generator=g),
-                   torch.randint(0, self.C, (self.B,), generator=g))
+            x = torch.rand(self.B, 3, self.size, self.size, generator=g)
+            t = torch.randint(0, self.C, (self.B,), generator=g)
+            yield (x, t) if self.shard is None else (x[lo:hi].contiguous(), t[lo:hi].contiguous())
+
+
+class ShardBatchSampler:
+    """Batch sampler of ONE rank: for every global batch b of `batch_size` consecutive samples (shuffle=False, drop_last=True:
+    classification_train_separately.py:675-681, quirk Q12) the indices of its rows [lo, hi) only -- the rank decodes, pins and
+    uploads its own slice of each batch and nothing else.  (lo, hi) = (0, batch_size) is the reference's loader."""
+
+    def __init__(self, n_samples: int, batch_size: int, lo: int, hi: int):
+        if not (0 <= lo <= hi <= batch_size):
+            raise ValueError(f"shard [{lo}, {hi}) outside the batch of {batch_size}")
+        self.n, self.B, self.lo, self.hi = int(n_samples), int(batch_size), int(lo), int(hi)
+
+    def __len__(self):
+        return self.n // self.B
+
+    def __iter__(self):
+        for b in range(self.n // self.B):
+            yield list(range(b * self.B + self.lo, b * self.B + self.hi))
 
 
 IMG_EXTENSIONS = (".jpg", ".jpeg", ".png", ".ppm", ".bmp", ".pgm", ".tif", ".tiff", ".webp")   # torchvision.datasets.folder
@@ -86,13 +111,21 @@ def get_dataset(args, config):
     return ImageFolderDataset(os.path.join(config.data.dataroot, split), base, args.preprocess)
 
 
-def get_test_loader(args, config):
+def get_test_loader(args, config, shard=None):
+    """The test loader of classification_train_separately.py:674-681 (batch_size from the config, no shuffle, drop_last).
+    shard = (lo, hi): this rank's rows of every global batch -- the loader then yields [hi - lo] images and their targets per
+    batch (attributes .shard / .global_batch say so), and only those files are opened."""
     n = int(getattr(args, "synthetic_batches", 0) or 0)
+    B = config.testing.batch_size
     if n > 0:
         size = int(round((config.model.data_dim / 3) ** 0.5))          # 224 for data_dim = 150528 (3 x 224 x 224)
         if 3 * size * size != config.model.data_dim:
             raise ValueError(f"model.data_dim={config.model.data_dim} is not 3 x S x S")
-        return SyntheticLoader(n, config.testing.batch_size, config.data.num_classes, seed=getattr(args, "seed", 0) or 0, size=size)
-    # classification_train_separately.py:674-681: batch_size from the config, no shuffle, drop_last (quirk Q12)
-    return torch.utils.data.DataLoader(get_dataset(args, config), batch_size=config.testing.batch_size, shuffle=False,
-                                       num_workers=int(getattr(config.data, "num_workers", 0) or 0), drop_last=True)
+        return SyntheticLoader(n, B, config.data.num_classes, seed=getattr(args, "seed", 0) or 0, size=size, shard=shard)
+    ds = get_dataset(args, config)
+    lo, hi = shard if shard is not None else (0, B)
+    loader = torch.utils.data.DataLoader(ds, batch_sampler=ShardBatchSampler(len(ds), B, lo, hi),
+                                         num_workers=int(getattr(config.data, "num_workers", 0) or 0))
+    loader.shard = (lo, hi) if shard is not None else None
+    loader.global_batch = B
+    return loader

@@ -149,6 +149,25 @@ class EnsembleEngine:
                                    self._stream()), "nd_p_sample")
         return out
 
+    def set_loop_form(self, one_launch: bool, skew_us: float = -1.0) -> None:
+        """Form of the T-step loop (nd_set_loop_form): per-step kernel nodes of a hipGraph, or ONE launch per p_sample_loop where
+        the shape allows (same bits; needs the device to itself while it runs).  skew_us < 0 keeps the current member skew."""
+        check(self.lib.nd_set_loop_form(self.h, 1 if one_launch else 0, float(skew_us)), "nd_set_loop_form")
+
+    def loop_form(self) -> str:
+        """'one_launch' or 'graph_nodes': what the most recently recorded / enqueued sampling loop ran as."""
+        return "one_launch" if self.lib.nd_loop_form(self.h) else "graph_nodes"
+
+    def persist_status(self, reset: bool = False) -> bool:
+        """True when no barrier wait of a one-launch loop has been abandoned (synchronises the device); raises otherwise."""
+        rc = self.lib.nd_persist_status(self.h, 1 if reset else 0)
+        if rc < 0:
+            check(rc, "nd_persist_status")
+        if rc != 0:
+            raise _lib.NdError("one-launch sampling loop: a barrier wait was abandoned (the grid was not resident at once -- another "
+                               "process on this device?); results of that call are invalid.  ND_PERSIST=0 selects the per-step form")
+        return True
+
     def set_profiling(self, enable: bool) -> None:
         check(self.lib.nd_set_profiling(self.h, 1 if enable else 0), "nd_set_profiling")
 
@@ -195,8 +214,9 @@ class EnsembleEngine:
             # MT = row fragments per pass (nd_pick_mt), grid = (workgroups, row passes, k-slabs)
             o6 = (C.c_int * 6)()
             check(self.lib.nd_skinny_plan(self.F, self.F, int(M), int(n_members), self.dtype, 1, o6), "nd_skinny_plan")
-            f = (int(M) + 15) // 16
-            mt = 1 if M <= 16 else 2 if M <= 32 else (5 if (f + 4) // 5 < (f + 3) // 4 else 4)
+            mt = self.lib.nd_skinny_row_fragments(int(M))             # the launcher's own choice (nd_pick_mt), not a copy of it
+            if mt < 1:
+                check(mt, "nd_skinny_row_fragments")
             plan["stream"] = {"grid": (o6[0], o6[1], o6[2]), "NF": o6[3], "MT": mt, "chunks_per_slab": o6[4], "threads": o6[5]}
         return plan
 

@@ -19,6 +19,28 @@ from . import _lib
 from .engine import EnsembleEngine
 
 
+class _TensorKey:
+    """Identity of a tensor's CONTENTS for the two caches below, in a form the caching allocator cannot forge.
+
+    (data_ptr, _version, shape) alone is not enough: a NEW tensor placed at the freed address of the previous one (same
+    shape, _version 0) -- `x = img.cuda().flatten(1)` per batch, or any loop that drops the old batch before it builds the next --
+    carries the same triple.  The key therefore also holds a weak reference to the tensor's untyped storage object (torch keeps
+    ONE Python object per live storage): a storage that has been freed is a dead reference, a recycled address is a different
+    object, and both read as "changed".  Views of one storage share it and share its version counter, so re-flattening the
+    same batch still hits."""
+
+    __slots__ = ("storage", "meta")
+
+    def __init__(self, t: torch.Tensor):
+        self.storage = weakref.ref(t.untyped_storage())
+        self.meta = (t.data_ptr(), t._version, tuple(t.shape), tuple(t.stride()), t.dtype, str(t.device))
+
+    def matches(self, t: torch.Tensor) -> bool:
+        alive = self.storage()
+        return (alive is not None and alive is t.untyped_storage()
+                and self.meta == (t.data_ptr(), t._version, tuple(t.shape), tuple(t.stride()), t.dtype, str(t.device)))
+
+
 class ConditionalLinear(nn.Module):
     """latent_model.py:93-105: parameter container (lin: Linear, embed: Embedding(n_steps, num_out))."""
 
@@ -67,8 +89,13 @@ class ConditionalModel(nn.Module):
         self._enc_sig = None
 
     # -- HIP engine, rebuilt when the parameters move or change --------------------------------
-    def _signature(self):
-        return tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
+    def _tensors(self):
+        return list(self.parameters()) + list(self.buffers())
+
+    def _signature_matches(self) -> bool:
+        ts = self._tensors()
+        return (self._engine_sig is not None and len(ts) == len(self._engine_sig)
+                and all(k.matches(t) for k, t in zip(self._engine_sig, ts)))
 
     def hip_engine(self) -> EnsembleEngine:
         if self.training:
@@ -76,23 +103,24 @@ class ConditionalModel(nn.Module):
         dev = next(self.parameters()).device
         if dev.type != "cuda":
             raise _lib.NdError("ConditionalModel.forward needs the parameters on the GPU (.to('cuda')); no CPU fallback")
-        sig = self._signature()
-        if self._engine is None or self._engine_sig != sig:
+        if self._engine is None or not self._signature_matches():
             C, D, H, F, T = self.dims
             if self._engine is None or self._engine.device != dev:
                 self._engine = EnsembleEngine(C, D, H, F, T, n_members=1, max_batch=self.max_batch, max_rows=self.max_rows,
                                               device=dev)
             self._engine.load_member(0, self.state_dict())      # [F, C] lin1 of guidance=False is widened there
-            self._engine_sig, self._enc_sig = sig, None
+            self._engine_sig, self._enc_sig = [_TensorKey(t) for t in self._tensors()], None
         return self._engine
 
     def encode(self, x: torch.Tensor) -> None:
-        """xe = norm(encoder_x(x)) (latent_model.py:170-171), cached per input tensor."""
+        """xe = norm(encoder_x(x)) (latent_model.py:170-171: evaluated on every call there), cached here while `x` is provably
+        the tensor contents of the last call (_TensorKey: live storage object + address + version counter + geometry), so the T
+        calls of a p_sample_loop and the mc_trials loops over one batch (classification_train_separately.py:770-777) encode once."""
         eng = self.hip_engine()
-        sig = (x.data_ptr(), x._version, tuple(x.shape), str(x.device))
-        if self._enc_sig != sig:
+        if self._enc_sig is None or not self._enc_sig.matches(x):
+            self._enc_sig = None            # a failed encode must not leave a stale key behind
             eng.encode(x)
-            self._enc_sig = sig
+            self._enc_sig = _TensorKey(x)
 
     def forward(self, x, y, t, yhat=None):
         """eps_theta(x, y_t, t, yhat) -> [B, C] (latent_model.py:169-184)."""

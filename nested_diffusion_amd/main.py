@@ -152,7 +152,7 @@ def parse_config(args):
 def set_seed(seed: int) -> None:
     """main.py:277-281 (torch, numpy, cuda); the runner's own set_seed (classification_train_separately.py:31-38, from
     Diffusion.__init__) adds python `random`, which random_cover_new's rectangles come from.  All ranks of a multi-GPU
-    run use the same seed: the runner draws per WHOLE batch and slices its shard (runner.draw_noise / shard_of_batch)."""
+    run use the same seed: the runner makes the random draws of a WHOLE batch and applies its own rows of them (runner.perturb / draw_noise)."""
     from .runner import set_seed as runner_set_seed
     runner_set_seed(seed)
 

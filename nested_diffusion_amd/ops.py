@@ -213,13 +213,22 @@ def qkv_images_supported(N: int, heads: int) -> bool:
     return bool(_lib.load().nd_qkv_images_supported(int(N), int(heads)))
 
 
-def gemm_split_qkv(x: SplitMatrix, weight: SplitMatrix, bias: Optional[torch.Tensor], B: int, N: int, heads: int) -> torch.Tensor:
+def gemm_split_qkv(x: SplitMatrix, weight: SplitMatrix, bias: Optional[torch.Tensor], B: int, N: int, heads: int,
+                   out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """The qkv Linear of a ViT block (x: image of [B*N, K], weight: image of [3*heads*64, K]) with its result written as the attention's
-    operand images (per image and head: q, k as frag32b3 blocks, v transposed; csrc/nd_b9.hpp).  Returns the opaque image buffer."""
+    operand images (per image and head: q, k as frag32b3 blocks, v transposed; csrc/nd_b9.hpp).  Returns the opaque image buffer.
+    out: an existing uint8 buffer of nd_qkv_images_bytes(B, N, heads) bytes to write into (rows / keys past N are never written:
+    whatever it held stays there)."""
     lib = _lib.load()
     if x.rows != B * N or weight.rows != 3 * heads * 64 or weight.K != x.K:
         raise ValueError(f"x is {x.shape}, weight {weight.shape}: expected [{B * N}, K] and [{3 * heads * 64}, K]")
-    img = torch.empty(lib.nd_qkv_images_bytes(B, N, heads), dtype=torch.uint8, device=x.device)
+    nbytes = lib.nd_qkv_images_bytes(B, N, heads)
+    if out is None:
+        img = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    else:
+        if out.dtype != torch.uint8 or not out.is_cuda or not out.is_contiguous() or out.numel() != nbytes or out.device != x.device:
+            raise ValueError(f"out must be a contiguous uint8 GPU buffer of {nbytes} bytes on {x.device}")
+        img = out
     check(lib.nd_gemm_split_qkv(ptr(x.data), ptr(weight.data), ptr(_f32(bias, "bias")) if bias is not None else None, ptr(img), B, N, heads, x.K,
                                 _stream(x.data)), "nd_gemm_split_qkv")
     return img

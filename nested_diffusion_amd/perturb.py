@@ -100,6 +100,18 @@ def random_cover_new(images_in: torch.Tensor, params: Sequence[float], rects=Non
     return x
 
 
+def pick_crop_corners(n_images: int, W: int, k: float):
+    """The corner draws of random_crop_and_resize (utils.py:296-300): per image `left` then `top`, torch.randint on the host
+    generator, in the reference's order."""
+    crop = int(W * (1 - k))
+    corners = []
+    for _ in range(n_images):
+        left = torch.randint(0, W - crop + 1, (1,)).item()
+        top = torch.randint(0, W - crop + 1, (1,)).item()
+        corners.append((top, left))
+    return corners
+
+
 def random_crop_and_resize(images_in: torch.Tensor, k: float, corners=None) -> torch.Tensor:
     """utils.py:282-312: per image a random square of side int(W * (1 - k)) (left drawn before top, torch.randint),
     resized back to (H, W) with torchvision's tensor Resize = bilinear interpolate, align_corners=False."""
@@ -107,10 +119,6 @@ def random_crop_and_resize(images_in: torch.Tensor, k: float, corners=None) -> t
     B, C, H, W = x.shape
     crop = int(W * (1 - k))
     if corners is None:
-        corners = []
-        for _ in range(B):
-            left = torch.randint(0, W - crop + 1, (1,)).item()
-            top = torch.randint(0, W - crop + 1, (1,)).item()
-            corners.append((top, left))
+        corners = pick_crop_corners(B, W, k)
     c = torch.tensor(corners, dtype=torch.int32, device=x.device).reshape(B, 2).contiguous()
     return _resize(x, H, W, crop=c, crop_size=crop)

@@ -94,6 +94,7 @@ class Diffusion(object):
         self._states = noise_estimator_states
         self.engine: Optional[EnsembleEngine] = None
         self.members: List[int] = []
+        self.bytes_uploaded = 0          # image bytes this rank has sent over PCIe (its shard of every batch, nothing else)
 
     # ---- conditioner -------------------------------------------------------------------------
     def compute_guiding_prediction(self, x, include_full_vit: bool = True):
@@ -184,10 +185,63 @@ class Diffusion(object):
         return z[:, :, :, lo:hi].reshape(K, T, mc * (hi - lo), C).contiguous()
 
     def shard_of_batch(self, images_raw: torch.Tensor, lo: int, hi: int) -> torch.Tensor:
-        """Perturb the WHOLE batch (:726-737; every rank makes the same host/device RNG calls in the reference's order,
-        so the windows and the noise of image i do not depend on the world size), then keep this rank's rows."""
-        images = self.perturb(images_raw.to(self.device, torch.float32))
-        return images[lo:hi].contiguous()
+        """Rows [lo, hi) of a HOST batch, uploaded and perturbed (:722-737).  Only the shard crosses PCIe; the random choices of the
+        perturbations are made for the WHOLE batch (perturb), so image i is treated alike at any world size."""
+        B_total = images_raw.shape[0]
+        x = images_raw[lo:hi].to(self.device, torch.float32)
+        self.bytes_uploaded += x.numel() * 4
+        return self.perturb(x, lo, hi, B_total)
+
+    def _rank_batches(self, test_loader, lo: int, hi: int, B_total: int):
+        """The rank's slice of every batch of the loader, on the device, ONE BATCH AHEAD: yields (images [hi-lo, 3, S, S] perturbed,
+        targets [hi-lo] on the device).  A loader that is already sharded (data.get_test_loader(shard=...): its .shard attribute)
+        hands over the rank's rows only -- only those files were decoded; a full-batch loader (the reference's, or a caller's) is
+        sliced on the HOST.  The slice goes through a pinned staging buffer and a non-blocking copy on a side stream into one of two
+        device buffers, issued before batch n's graph is launched, so batch n + 1's PCIe transfer runs under batch n's compute
+        (classification_train_separately.py:722 is a blocking .to(device) of the whole batch on the compute stream)."""
+        main = torch.cuda.current_stream(self.device)
+        side = torch.cuda.Stream(self.device)
+        sharded = getattr(test_loader, "shard", None) == (lo, hi)
+        pins, bufs, evs = [None, None], [None, None], [None, None]
+
+        def stage(k, item):
+            images_raw, target = item
+            x = images_raw if sharded else images_raw[lo:hi]
+            t = target if sharded else target[lo:hi]
+            if x.shape[0] != hi - lo:
+                raise ValueError(f"loader handed {x.shape[0]} rows for the shard [{lo}, {hi})")
+            if x.is_cuda:                                   # a caller's loader that already lives on the device
+                return x.to(self.device, torch.float32), t.to(self.device), None
+            if pins[k] is None or pins[k].shape != x.shape:
+                pins[k] = torch.empty(x.shape, dtype=torch.float32, pin_memory=True)
+                bufs[k] = torch.empty(x.shape, dtype=torch.float32, device=self.device)
+            if evs[k] is not None:
+                evs[k].synchronize()                        # the copy that last read this staging buffer (two batches ago)
+            pins[k].copy_(x)
+            side.wait_stream(main)                          # bufs[k]'s last reader (batch n - 1, already enqueued) before it is overwritten
+            with torch.cuda.stream(side):
+                bufs[k].copy_(pins[k], non_blocking=True)
+                evs[k] = torch.cuda.Event()
+                evs[k].record(side)
+            self.bytes_uploaded += x.numel() * 4
+            return bufs[k], t.to(self.device, non_blocking=True), evs[k]
+
+        it = iter(test_loader)
+        nxt = None
+        k = 0
+        for item in it:
+            cur, nxt = nxt, stage(k, item)
+            k ^= 1
+            if cur is not None:
+                yield self._finish_batch(cur, main, lo, hi, B_total)
+        if nxt is not None:
+            yield self._finish_batch(nxt, main, lo, hi, B_total)
+
+    def _finish_batch(self, staged, main, lo, hi, B_total):
+        x, t, ev = staged
+        if ev is not None:
+            main.wait_event(ev)
+        return self.perturb(x, lo, hi, B_total), t
 
     # ---- temperature calibration (:449-629, driven by main.py:356-361) ---------------------------
     def test_calibrate(self, temp=None, test_loader=None):
@@ -199,24 +253,24 @@ class Diffusion(object):
             self.temperature = float(temp[0] if hasattr(temp, "__len__") else temp)
         resample = bool(int(os.environ.get("ND_CALIB_RESAMPLE", "0")))
         if resample or getattr(self, "_calib_cache", None) is None:
-            if test_loader is None:
-                from .data import get_test_loader
-                test_loader = get_test_loader(self.args, self.config)
             rank, world = nd_dist.rank_world()
             B = self.config.testing.batch_size
             lo, hi = nd_dist.shard_bounds(B, rank, world)
+            if test_loader is None:
+                from .data import get_test_loader
+                test_loader = get_test_loader(self.args, self.config, shard=(lo, hi) if world > 1 else None)
             if self.engine is None:
                 self.load_noise_estimators(max_batch=max(hi - lo, 1))
             self._seed_noise(lo)
             samples, targets = [], []
-            for images_raw, target in test_loader:
-                images = self.shard_of_batch(images_raw, lo, hi)
+            for images, target in self._rank_batches(test_loader, lo, hi, B):
                 out = self.predict_batch(images)
                 S = out["samples"].shape[0]
-                flat = out["samples"].permute(1, 0, 2).reshape(hi - lo, -1).contiguous()      # [B_local, S*C]
+                flat = out["samples"].permute(1, 0, 2).reshape(hi - lo, -1)                      # [B_local, S*C]
+                flat = torch.cat([flat, target.to(torch.float32)[:, None]], dim=1).contiguous()  # + the rows' targets
                 flat = nd_dist.all_gather_rows(flat, B, world)
-                samples.append(flat.reshape(B, S, -1).permute(1, 0, 2).contiguous())
-                targets.append(target.to(self.device))
+                samples.append(flat[:, :-1].reshape(B, S, -1).permute(1, 0, 2).contiguous())
+                targets.append(flat[:, -1].to(torch.int64))
             self._calib_cache = (torch.cat(samples, dim=1).contiguous(), torch.cat(targets))
         samples, targets = self._calib_cache
         prob, vote, _ = ops.aggregate(samples, self.temperature)              # compute_ensemble_confidence (:612)
@@ -227,11 +281,22 @@ class Diffusion(object):
         return ece
 
     # ---- input perturbations (:726-737), in the reference's order ------------------------------
-    def perturb(self, images_224: torch.Tensor) -> torch.Tensor:
+    def perturb(self, images_224: torch.Tensor, lo: int = 0, hi: Optional[int] = None, B_total: Optional[int] = None) -> torch.Tensor:
+        """images_224: rows [lo, hi) of a test batch of B_total images (default: the whole batch).  Every rank holds the same
+        --seed (set_seed, :31-38) and makes the reference's RNG calls for the WHOLE batch in the reference's order -- the device
+        draw of add_noise (utils.py:274), python `random` for the cover rectangles (:321-343), torch.randint for the crop corners
+        (:296-300) -- and applies rows [lo, hi) of them to its own images: image i gets the same noise, windows and crops at
+        world 1, 2, 4, 8, and only the shard's pixels are ever moved or touched."""
         from . import perturb as P
         a = self.args
+        n_local = images_224.shape[0]
+        hi = lo + n_local if hi is None else hi
+        B_total = n_local if B_total is None else B_total
+        if hi - lo != n_local or not (0 <= lo <= hi <= B_total):
+            raise ValueError(f"perturb: {n_local} rows for the shard [{lo}, {hi}) of {B_total}")
         if (getattr(a, "noise_perturbation", 0.0) or 0.0) > 0.0:
-            images_224 = P.add_noise(images_224, a.noise_perturbation)
+            z = torch.randn((B_total,) + tuple(images_224.shape[1:]), dtype=torch.float32, device=images_224.device)
+            images_224 = P.add_noise(images_224, a.noise_perturbation, z=z[lo:hi])
         if (getattr(a, "low_resolution", 0) or 0) > 1:
             images_224 = P.down_up_sample(images_224, a.low_resolution)
         if (getattr(a, "brightness", 0.0) or 0.0) != 0.0:
@@ -240,9 +305,12 @@ class Diffusion(object):
             images_224 = P.adjust_contrast(images_224, a.contrast)
         covered = getattr(a, "covered", (0.0, 0.0)) or (0.0, 0.0)
         if covered[0] > 0:
-            images_224 = P.random_cover_new(images_224, covered)
+            H, W = images_224.shape[-2:]
+            _, rects = P.pick_cover_regions(B_total, H, W, covered[0], int(covered[1]))
+            images_224 = P.random_cover_new(images_224, covered, rects=rects[lo:hi])
         if (getattr(a, "crop", 0.0) or 0.0) > 0:
-            images_224 = P.random_crop_and_resize(images_224, a.crop)
+            corners = P.pick_crop_corners(B_total, images_224.shape[-1], a.crop)
+            images_224 = P.random_crop_and_resize(images_224, a.crop, corners=corners[lo:hi])
         return images_224
 
     # ---- test loop ----------------------------------------------------------------------------
@@ -252,28 +320,27 @@ class Diffusion(object):
         args, config = self.args, self.config
         if getattr(args, "attack_name", None) not in (None, "None"):
             raise NotImplementedError("adversarial attacks need gradients through the ViT: out of scope")
-        if test_loader is None:
-            from .data import get_test_loader
-            test_loader = get_test_loader(args, config)
         rank, world = nd_dist.rank_world()
         B = config.testing.batch_size
         lo, hi = nd_dist.shard_bounds(B, rank, world)
+        if test_loader is None:
+            from .data import get_test_loader
+            test_loader = get_test_loader(args, config, shard=(lo, hi) if world > 1 else None)   # each rank decodes its own rows only
         self.load_noise_estimators(max_batch=max(hi - lo, 1))
         # the sampler's draws come from the library's counter-based generator keyed on the GLOBAL image index (lo = this rank's
         # first image) and the batch counter: image i sees the same K*T*mc draws at any world size
         self._seed_noise(lo)
         mv_class, target_class, prob_mc, piw_mc, var_mc = [], [], [], [], []
         n_step_img, t0 = 0, time.time()
-        for images_raw, target in test_loader:
-            images = self.shard_of_batch(images_raw, lo, hi)                 # :726-737
+        for images, target in self._rank_batches(test_loader, lo, hi, B):   # :715-737, this rank's rows only
             out = self.predict_batch(images, clone=False)
             # spread of the K*mc per-sample probabilities per image (what the reference keeps in pred_mc, quirk Q4)
             piw, var = ops.sample_stats(out["probs"])
-            packed = torch.cat([out["prob"], piw, var, out["vote"].to(torch.float32)[:, None]], dim=1)
+            packed = torch.cat([out["prob"], piw, var, out["vote"].to(torch.float32)[:, None], target.to(torch.float32)[:, None]], dim=1)
             packed = nd_dist.all_gather_rows(packed, B, world)               # the single RCCL all-gather of a batch
             C = out["prob"].shape[1]
             prob_mc.append(packed[:, :C]); piw_mc.append(packed[:, C:2 * C]); var_mc.append(packed[:, 2 * C:3 * C])
-            mv_class.append(packed[:, 3 * C].to(torch.int64)); target_class.append(target.to(self.device))
+            mv_class.append(packed[:, 3 * C].to(torch.int64)); target_class.append(packed[:, 3 * C + 1].to(torch.int64))
             n_step_img += B * len(self.members) * self.mc_trials * self.num_timesteps
         torch.cuda.synchronize(self.device)
         dt = time.time() - t0

@@ -1,7 +1,7 @@
 """Child process of tests/test_gpu_configs.py: one rank (or the single process) of BASELINE configs[3]'s PER-RANK workload at
 config dims -- K = 5 members, T = 100, D = 150528, F = H = 4096, fp32 -- running Diffusion.test_atk on ONE global test batch.
-Every rank builds the same seeded synthetic weights, perturbs / draws for the whole batch and keeps its shard
-(runner.shard_of_batch / draw_noise), samples, and takes part in the batch's single all-gather.  Rank 0 writes the gathered
+Every rank builds the same seeded synthetic weights, uploads and perturbs ITS rows of the batch with the random choices made for
+the whole batch (runner._rank_batches / perturb), samples, and takes part in the batch's single all-gather.  Rank 0 writes the gathered
 class probabilities and votes.  World size, rank and rendezvous come from the environment (as under torch.distributed.run)."""
 import argparse
 import os

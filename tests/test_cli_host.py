@@ -133,3 +133,33 @@ def test_bench_launcher_propagates_a_failing_rank(tmp_path, monkeypatch):
     monkeypatch.delenv("ND_DIST_BACKEND", raising=False)
     with pytest.raises(SystemExit, match="visible"):
         bench.launch_ranks(2, ["--gpus", "2"])
+
+
+def test_tensor_key_cannot_be_forged_by_a_recycled_address():
+    """latent_model._TensorKey (the cache key of ConditionalModel.encode and of the engine's parameter signature): a new tensor at
+    the freed address of the old one, same shape and version counter, is NOT the old tensor; a view of the same live storage is;
+    an in-place edit is not.  CPU tensors: the host allocator recycles freed blocks just like the device's caching allocator."""
+    import torch
+    from nested_diffusion_amd.latent_model import _TensorKey
+    hit = False
+    for _ in range(32):
+        a = torch.zeros(1 << 16)
+        key, ptr = _TensorKey(a), a.data_ptr()
+        assert key.matches(a) and key.matches(a.view(256, 256).view(-1))
+        assert not key.matches(a[1:])                    # same storage, another window
+        del a
+        b = torch.zeros(1 << 16)
+        if b.data_ptr() == ptr:
+            hit = True
+            assert b._version == 0 and tuple(b.shape) == (1 << 16,)
+            assert not key.matches(b), "a recycled address passed for the freed tensor"
+            break
+    if not hit:
+        pytest.skip("the host allocator never handed the freed block back")
+    c = torch.zeros(8)
+    k = _TensorKey(c)
+    c.add_(1)
+    assert not k.matches(c)                              # version counter
+    k = _TensorKey(c)
+    c.view(2, 4)[0, 0] = 5                               # ... shared with every view
+    assert not k.matches(c)

@@ -92,3 +92,100 @@ def test_single_process_is_a_noop():
     assert nd_dist.rank_world() == (0, 1)
     x = torch.arange(6.0).reshape(3, 2)
     assert nd_dist.all_gather_rows(x, 3, 1) is x
+
+
+# ---- the DATA path is sharded too: a rank decodes, stages and uploads its own rows of every batch and nothing else ----------------
+class _CountingDataset(torch.utils.data.Dataset):
+    """23 'images' whose pixels encode their index; counts which samples were opened."""
+
+    def __init__(self, n=23):
+        self.n, self.opened = n, []
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        self.opened.append(i)
+        return torch.full((3, 4, 4), float(i)), i % 2
+
+
+@pytest.mark.parametrize("world", [1, 2, 8])
+def test_shard_batch_sampler_opens_only_the_ranks_rows(world):
+    """data.ShardBatchSampler through a real DataLoader: batch b of the reference's loader (batch_size B, shuffle=False, drop_last=True,
+    classification_train_separately.py:675-681) is rows b*B .. b*B + B - 1; rank r is handed rows [lo, hi) of it in order, opens exactly
+    those samples, and the ranks' slices concatenated in rank order are the world-1 batches.  Ragged split (B = 10 over 8 ranks)."""
+    from nested_diffusion_amd import dist as nd_dist
+    from nested_diffusion_amd.data import ShardBatchSampler
+    B, n = 10, 23
+    ref_ds = _CountingDataset(n)
+    ref = [x for x in torch.utils.data.DataLoader(ref_ds, batch_size=B, shuffle=False, drop_last=True)]
+    assert len(ref) == 2
+    pieces = [[] for _ in ref]
+    for r in range(world):
+        lo, hi = nd_dist.shard_bounds(B, r, world)
+        ds = _CountingDataset(n)
+        loader = torch.utils.data.DataLoader(ds, batch_sampler=ShardBatchSampler(len(ds), B, lo, hi))
+        got = list(loader)
+        assert len(got) == len(ref) == len(loader)                                  # drop_last on the GLOBAL batch
+        for b, (x, t) in enumerate(got):
+            assert tuple(x.shape) == (hi - lo, 3, 4, 4) and tuple(t.shape) == (hi - lo,)
+            pieces[b].append((x, t))
+        assert ds.opened == [b * B + i for b in range(len(ref)) for i in range(lo, hi)]      # nothing but its own rows was decoded
+        assert len(ds.opened) * 3 * 4 * 4 * 4 == sum(x.numel() * 4 for x, _ in got)          # bytes staged = the shard's bytes
+    for b, (x_ref, t_ref) in enumerate(ref):
+        assert torch.equal(torch.cat([x for x, _ in pieces[b]]), x_ref) and torch.equal(torch.cat([t for _, t in pieces[b]]), t_ref)
+    with pytest.raises(ValueError):
+        ShardBatchSampler(23, 10, 4, 11)
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_synthetic_loader_shard_is_a_slice_of_the_global_batch(world):
+    from nested_diffusion_amd import dist as nd_dist
+    from nested_diffusion_amd.data import SyntheticLoader
+    B = 16
+    full = list(SyntheticLoader(2, B, 2, seed=5, size=8))
+    for r in range(world):
+        lo, hi = nd_dist.shard_bounds(B, r, world)
+        mine = SyntheticLoader(2, B, 2, seed=5, size=8, shard=(lo, hi))
+        assert mine.shard == (lo, hi) and mine.global_batch == B
+        for (x, t), (xf, tf) in zip(mine, full):
+            assert torch.equal(x, xf[lo:hi]) and torch.equal(t, tf[lo:hi])
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_perturbations_of_image_i_do_not_depend_on_the_world_size(world, monkeypatch):
+    """runner.Diffusion.perturb on a shard: every rank (same --seed: set_seed, classification_train_separately.py:31-38) makes the
+    reference's random calls for the WHOLE batch -- the draw of add_noise (utils.py:274), python `random` for the cover rectangles
+    (:321-343), torch.randint for the crop corners (:296-300) -- and applies rows [lo, hi) of them.  The pixel kernels are replaced by
+    recorders here (no GPU in this suite): what is checked is that rank r is handed exactly rows [lo, hi) of the world-1 parameters,
+    with --noise_perturbation / --covered / --crop all on, over two consecutive batches."""
+    import argparse
+    from nested_diffusion_amd import dist as nd_dist, perturb as P
+    from nested_diffusion_amd.runner import Diffusion, set_seed
+    B, H = 16, 12
+    args = argparse.Namespace(noise_perturbation=0.1, low_resolution=0, brightness=0.0, contrast=1.0, covered=(0.05, 2.0), crop=0.25)
+    log = []
+    monkeypatch.setattr(P, "add_noise", lambda x, std, z=None: (log.append(("noise", z.clone())), x)[1])
+    monkeypatch.setattr(P, "random_cover_new", lambda x, params, rects=None: (log.append(("cover", list(rects))), x)[1])
+    monkeypatch.setattr(P, "random_crop_and_resize", lambda x, k, corners=None: (log.append(("crop", list(corners))), x)[1])
+    fake = argparse.Namespace(args=args)
+
+    def run(lo, hi):
+        log.clear()
+        set_seed(123)
+        for _ in range(2):                                                           # two batches: the generators run on between them
+            Diffusion.perturb(fake, torch.zeros(hi - lo, 3, H, H), lo, hi, B)
+        return list(log)
+
+    whole = run(0, B)
+    assert [k for k, _ in whole] == ["noise", "cover", "crop"] * 2
+    for r in range(world):
+        lo, hi = nd_dist.shard_bounds(B, r, world)
+        mine = run(lo, hi)
+        for (kind, got), (_, ref) in zip(mine, whole):
+            if kind == "noise":
+                assert tuple(got.shape) == (hi - lo, 3, H, H) and torch.equal(got, ref[lo:hi])
+            else:
+                assert got == ref[lo:hi] and len(got) == hi - lo
+    with pytest.raises(ValueError):
+        Diffusion.perturb(fake, torch.zeros(3, 3, H, H), 2, 6, B)                    # 3 rows handed for a shard of 4

@@ -247,7 +247,7 @@ def _write_image_tree(root):
 def test_main_test_path_from_image_files_on_disk(tmp_path, capsys, monkeypatch):
     """SURVEY 8(f)-4 end to end on the GPU: PNG / JPEG files on disk -> ImageFolder ordering + Grayscale(3) / Resize(224) / ToTensor
     (dataset_helper/chest_x_ray_dataset.py:28-51) -> DataLoader(batch_size from the YAML, shuffle=False, drop_last=True)
-    (classification_train_separately.py:674-681) -> the batch loop of test_atk (:715-722) -> shard_of_batch -> nd_predict_batch ->
+    (classification_train_separately.py:674-681) -> the batch loop of test_atk (:715-722: pinned staging, side-stream upload) -> nd_predict_batch ->
     nd_report -- with NO --synthetic_batches.  7 images, batch 3: two batches, the 7th image dropped.  Checked: (i) through the literal
     entry point scripts/diffusion/main.py in a fresh interpreter with --dataroot (main.py:184-185) and two loader worker processes:
     rc 0, the report lines, no traceback; (ii) in-process with the batch loop observed: number of batches and images consumed, targets
@@ -282,11 +282,11 @@ def test_main_test_path_from_image_files_on_disk(tmp_path, capsys, monkeypatch):
         assert key in r.stdout, (key, r.stdout[-1500:])
     # (ii) in-process, the batch loop observed
     seen = {"raw": [], "targets": [], "runner": None}
-    orig_shard, orig_atk = runner_mod.Diffusion.shard_of_batch, runner_mod.Diffusion.test_atk
+    orig_perturb, orig_atk = runner_mod.Diffusion.perturb, runner_mod.Diffusion.test_atk
 
-    def spy_shard(self, images_raw, lo, hi):
-        seen["raw"].append(images_raw.clone())
-        return orig_shard(self, images_raw, lo, hi)
+    def spy_perturb(self, images_224, lo=0, hi=None, B_total=None):       # what the batch loop uploaded (:722), before :726-737
+        seen["raw"].append(images_224.cpu().clone())
+        return orig_perturb(self, images_224, lo, hi, B_total)
 
     def spy_atk(self, test_loader=None):
         seen["runner"] = self
@@ -297,7 +297,7 @@ def test_main_test_path_from_image_files_on_disk(tmp_path, capsys, monkeypatch):
         seen["targets"] = [t.clone() for _, t in batches]
         return orig_atk(self, test_loader=batches)
 
-    monkeypatch.setattr(runner_mod.Diffusion, "shard_of_batch", spy_shard)
+    monkeypatch.setattr(runner_mod.Diffusion, "perturb", spy_perturb)
     monkeypatch.setattr(runner_mod.Diffusion, "test_atk", spy_atk)
     argv = flags + ["--config", ypath, "--exp", os.path.join(str(tmp_path), "results_inproc")]
     assert nd_main.main(argv) == 0

@@ -81,7 +81,9 @@ def _worker(rank, world, port, out_dir, backend):
     shard_runner.test_atk(test_loader=[(x_cpu, target), (x_cpu.flip(0), target)])
     err2 = float((shard_runner.last_probs - probs_full).abs().max())
     ok2 = err2 <= 1e-6 and shard_runner.last_report["accuracy"] == acc_full
-    torch.save({"ok": bool(ok1 and ok2), "err_kernels": err1, "err_seeded_run": err2, "backend": backend},
+    # only the rank's rows of each of the two batches crossed PCIe (the loader hands whole batches here: sliced on the host)
+    ok2 = ok2 and shard_runner.bytes_uploaded == 2 * (hi - lo) * 3 * 32 * 32 * 4
+    torch.save({"ok": bool(ok1 and ok2), "err_kernels": err1, "err_seeded_run": err2, "backend": backend, "bytes_uploaded": shard_runner.bytes_uploaded},
                os.path.join(out_dir, f"r{rank}.pt"))
     td.barrier()
     td.destroy_process_group()

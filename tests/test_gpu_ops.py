@@ -233,11 +233,14 @@ def test_attention_on_the_bf16_pipe_from_qkv_images(B, N, heads):
     b = torch.randn(3 * E, generator=g) * 0.1
     assert ops.qkv_images_supported(N, heads)
     xs, ws = ops.split_rows(x.cuda()), ops.split_rows(w.cuda())
-    # poison the buffer the images will land in: rows / keys past N are never written and must not reach the result
+    # poison THE buffer the images land in (handed over explicitly: no reliance on the allocator recycling a block): rows / keys past N
+    # are never written and must not reach the result.  0xFF bytes = bf16 NaNs in every piece.
     nbytes = _lib.load().nd_qkv_images_bytes(B, N, heads)
-    junk = torch.full((nbytes // 4,), float("nan"), device="cuda")
-    del junk
-    img = ops.gemm_split_qkv(xs, ws, b.cuda(), B, N, heads)
+    buf = torch.full((nbytes,), 0xFF, dtype=torch.uint8, device="cuda")
+    img = ops.gemm_split_qkv(xs, ws, b.cuda(), B, N, heads, out=buf)
+    assert img.data_ptr() == buf.data_ptr()
+    if N % 16:                                                                            # a ragged last fragment: poison must survive in it
+        assert (buf == 0xFF).any()
     out = ops.attention_images(img, B, N, heads)
     qkv64 = x.double() @ w.double().T + b.double()
     t = qkv64.reshape(B, N, 3, heads, 64).permute(2, 0, 3, 1, 4)

@@ -41,6 +41,32 @@ def test_conditioner_vs_oracle_small_vit():
         assert err < 2e-5 * max(1.0, ref[k].abs().max().item()), (k, err)
 
 
+def test_conditioner_arena_poisoned_with_nans_changes_no_bit():
+    """The conditioner's activation arena (nd_cond workspace: token buffers, the attention's operand images, the mapping MLPs'
+    packed intermediates) filled with 0xFF bytes -- fp32 and bf16 NaNs everywhere -- before a call: every byte a kernel reads is
+    written first or masked (token rows past N = 196 in the last 16-row fragment and keys past N in the last key block of the qkv
+    images are NEVER written), so the logits must come out bit-identical to the call on a clean arena.  196 tokens: ragged last
+    fragment; B = 3: ragged last row tile of the mapping MLPs."""
+    from nested_diffusion_amd.mapping import Classifier, GuidingConditioner, VisionTransformer
+    embed, heads, depth, img, patch, K, B = 128, 2, 2, 224, 16, 2, 3
+    vp = ref_cpu.init_vit_params(embed=embed, depth=depth, patch=patch, img=img, seed=15)
+    n_tok = (img // patch) ** 2
+    mlps = [ref_cpu.init_classifier_params(n_tok * embed, widths=(256, 128, 64), seed=30 + i) for i in range(K)]
+    x = torch.rand(B, 3, img, img, generator=torch.Generator().manual_seed(2)).cuda()
+    cond = GuidingConditioner(VisionTransformer(vp, heads), [Classifier(m) for m in mlps])
+    assert cond.vit.split                                                      # the bf16 x 9 path with attention images
+    clean = [t.clone() for t in cond.compute_guiding_prediction(x, include_full_vit=False)]
+    assert all(torch.isfinite(t).all() for t in clean)
+    ref = ref_cpu.compute_guiding_prediction(vp, mlps, x.cpu(), heads, depth, full_vit=False, share_prefix=False)
+    for k in range(K):
+        assert (clean[k].cpu() - ref[k]).abs().max().item() < 2e-5 * max(1.0, ref[k].abs().max().item())
+    torch.cuda.synchronize()
+    cond._ws.fill_(0xFF)
+    poisoned = cond.compute_guiding_prediction(x, include_full_vit=False)
+    for a, b in zip(clean, poisoned):
+        assert torch.equal(a, b)
+
+
 def test_module_and_p_sample_loop_dropin():
     """ConditionalModel.load_state_dict(reference state) + p_sample_loop / p_sample / p_sample_t_1to0 with
     the reference's signatures reproduce the golden trajectory."""
@@ -75,6 +101,83 @@ def test_module_and_p_sample_loop_dropin():
     assert tuple(y_rand.shape) == (B, C) and torch.isfinite(y_rand).all()
     with pytest.raises(Exception):
         model.train()(x, yhat, torch.tensor([0]), yhat)        # inference only
+
+
+def test_new_batch_at_a_recycled_address_is_re_encoded():
+    """The encoder hoist is cached per input tensor (ConditionalModel.encode).  A NEW batch that the caching allocator places at the
+    freed address of the previous one (same shape, _version 0) must not get the previous batch's xe: the reference evaluates
+    encoder_x on every call (latent_model.py:169-171), and a per-batch `x = img.cuda().flatten(1)` (classification_train_separately.py:
+    744-747 without the old batch kept alive) recycles exactly like this.  (a) free x1, allocate x2 at the same address, sample
+    again: y_0 must be the oracle's for x2;  (b) an in-place edit of x re-encodes (version counter)."""
+    from nested_diffusion_amd import diffusion_utils as du
+    from nested_diffusion_amd.latent_model import ConditionalModel
+    z = np.load(os.path.join(G, "sampler_s0.npz"))
+    p = {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("p.")}
+    D, H, Fd, C, T, B, seed = [int(v) for v in z["dims"]]
+    model = ConditionalModel(small_config(D, H, Fd, C, T, B), guidance=True, max_batch=8)
+    model.load_state_dict(p, strict=True)
+    model = model.to("cuda").eval()
+    yhat, noise = (torch.from_numpy(z[k]).cuda() for k in ("yhat", "noise"))
+    alphas, omabs = torch.from_numpy(z["alphas"]).cuda(), torch.from_numpy(z["omabs"]).cuda()
+    x1_host = torch.from_numpy(z["x"])
+    x2_host = torch.randn(x1_host.shape, generator=torch.Generator().manual_seed(77)) * 4.0
+    params = {k: v.clone() for k, v in p.items()}
+
+    def oracle_y0(xh):
+        return ref_cpu.p_sample_loop(params, xh, yhat.cpu(), yhat.cpu(), T, alphas.cpu(), omabs.cpu(), noise.cpu()).numpy()
+
+    def tol(ref):
+        return 2e-5 * max(1.0, np.abs(ref).max())
+
+    def run(x):
+        return du.p_sample_loop(model, x, yhat, yhat, T, alphas, omabs, only_last_sample=True, noise=noise).cpu().numpy()
+
+    ref1, ref2 = oracle_y0(x1_host), oracle_y0(x2_host)
+    assert np.abs(ref1 - ref2).max() > 20 * max(tol(ref1), tol(ref2))       # the two batches differ in y_0 far beyond the tolerance
+    x1 = x1_host.cuda()
+    assert np.abs(run(x1) - ref1).max() < tol(ref1)
+    old_ptr = x1.data_ptr()
+    del x1
+    # (a) a fresh tensor of the same shape at the freed address; the allocator usually hands the block straight back
+    x2 = None
+    for _ in range(8):
+        cand = torch.empty(x1_host.shape, device="cuda")
+        if cand.data_ptr() == old_ptr:
+            x2 = cand
+            break
+        del cand
+    if x2 is None:
+        pytest.skip("the caching allocator never recycled the freed block")
+    x2.copy_(x2_host)                                            # version counter 1 -- so also the harder variant below
+    got = run(x2)
+    assert np.abs(got - ref2).max() < tol(ref2), "stale xe: the new batch was sampled with the previous batch's encoder output"
+    # the same with _version == 0 on both sides: build the batch elsewhere, free, and let torch.clone land on the old address
+    del x2
+    src = x1_host.cuda()
+    assert np.abs(run(src) - ref1).max() < tol(ref1)
+    ptr = src.data_ptr()
+    stage = x2_host.cuda()
+    del src
+    x3 = stage.clone()
+    if x3.data_ptr() == ptr:
+        assert x3._version == 0
+        assert np.abs(run(x3) - ref2).max() < tol(ref2), "stale xe at _version 0"
+    # (b) an in-place edit re-encodes
+    x4 = x1_host.cuda()
+    assert np.abs(run(x4) - ref1).max() < tol(ref1)
+    x4.copy_(x2_host.cuda())
+    assert np.abs(run(x4) - ref2).max() < tol(ref2)
+    # ... and a view of the same, unchanged storage does NOT (the T calls of a loop and re-flattened batches stay cached)
+    calls = []
+    eng = model.hip_engine()
+    real = eng.encode
+    eng.encode = lambda t: (calls.append(1), real(t))[1]
+    try:
+        assert np.abs(run(x4.view(B, -1)) - ref2).max() < tol(ref2)
+        assert np.abs(run(x4.reshape(B, D)) - ref2).max() < tol(ref2)
+    finally:
+        eng.encode = real
+    assert not calls, "a view of the cached batch was re-encoded"
 
 
 def test_guidance_false_model_vs_reference_golden():

@@ -34,15 +34,13 @@ for name, K, N, act, res in shapes:
         y = ops.gemm_split(xs, ws, b, act=act, residual=r)
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / reps * 1e3
-    os.environ["ND_GEMM_F32"] = "mfma_f32"
-    for _ in range(20):
+    for _ in range(20):                      # ops.gemm_bias_act on fp32 weights IS the f32-input-MFMA kernel (k_gemm_nt): no switch involved
         y32 = ops.gemm_bias_act(x, w, b, act=act, residual=r)
     torch.cuda.synchronize(); e0.record()
     for _ in range(reps):
         y32 = ops.gemm_bias_act(x, w, b, act=act, residual=r)
     e1.record(); torch.cuda.synchronize()
     us32 = e0.elapsed_time(e1) / reps * 1e3
-    del os.environ["ND_GEMM_F32"]
     ref = torch.nn.functional.linear(x.double(), w.double(), b.double())
     if act == "gelu":
         ref = torch.nn.functional.gelu(ref)

@@ -65,6 +65,32 @@ __device__ __forceinline__ void grid_barrier(Bar* b, unsigned gen, unsigned n_xc
     __syncthreads();
 }
 
+// flat per-MEMBER barrier (round 6): the G members' step chains are independent, so a barrier only has to join one member's workgroups.
+// No census, no XCD hierarchy: every workgroup releases (FENCE: its own agent-scope release fence; the write-back covers its XCD's L2)
+// and arrives at its member's counter; the last arriver publishes the member's generation word.
+struct MBar {
+    unsigned count[8][32];
+    unsigned gen[8][32];
+    unsigned err[32];
+};
+template <bool FENCE>
+__device__ __forceinline__ void member_barrier(MBar* b, int g, unsigned gen, unsigned n_here) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (FENCE) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        const unsigned old = __hip_atomic_fetch_add(&b->count[g][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old + 1 == n_here * gen) st_sc1(&b->gen[g][0], gen);
+        long long t0 = wall_clock64();
+        while (ld_sc1(&b->gen[g][0]) < gen) {
+            __builtin_amdgcn_s_sleep(1);
+            if (wall_clock64() - t0 > 200000000ll) { st_sc1(&b->err[0], 1u); break; }
+        }
+        if (FENCE) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    }
+    __syncthreads();
+}
+
 struct P {
     const float* w[2];       // two layers' weights, G * 64 MiB each
     const float* x;          // activations (512 KB per member)
@@ -143,6 +169,25 @@ __global__ __launch_bounds__(256) void k_persist(P p, Bar* b, int steps, unsigne
     }
 }
 
+template <bool PRE, bool WORK, bool FENCE>
+__global__ __launch_bounds__(256) void k_persist_m(P p, MBar* b, int steps, unsigned gen0) {
+    const int wg = blockIdx.x, nwg = gridDim.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wpm = nwg / p.G, g = wg / wpm;
+    unsigned gen = gen0;
+    f32x4 pre[4];
+    for (int it = 0; it < steps; ++it) {
+        if (WORK) head_body(p, wg, nwg, it);
+        if (PRE && WORK) for (int u = 0; u < 4; ++u) pre[u] = ld_nt(p.w[0] + ((size_t)(wg * 4 + wave) * p.kib_per_wave + u) * 256 + lane * 4);
+        member_barrier<FENCE>(b, g, ++gen, wpm);
+        if (WORK) layer_body<PRE>(p, 0, wg, pre, true, p.out);
+        if (PRE && WORK) for (int u = 0; u < 4; ++u) pre[u] = ld_nt(p.w[1] + ((size_t)(wg * 4 + wave) * p.kib_per_wave + u) * 256 + lane * 4);
+        member_barrier<FENCE>(b, g, ++gen, wpm);
+        if (WORK) layer_body<PRE>(p, 1, wg, pre, true, p.out);
+        member_barrier<FENCE>(b, g, ++gen, wpm);
+    }
+}
+
 int main(int argc, char** argv) {
     const int G = argc > 1 ? atoi(argv[1]) : 1, steps = argc > 2 ? atoi(argv[2]) : 100, reps = argc > 3 ? atoi(argv[3]) : 5;
     int ncu = 0;
@@ -214,8 +259,23 @@ int main(int argc, char** argv) {
     const float t_bar = timeit("persistent: barriers only", [&] { run_persist(k_persist<false, false>); });
     const float t_p = timeit("persistent", [&] { run_persist(k_persist<false, true>); });
     const float t_pp = timeit("persistent + prefetch", [&] { run_persist(k_persist<true, true>); });
+    // --- flat per-member barriers ---
+    MBar* mbar; CK(hipMalloc(&mbar, sizeof(MBar))); CK(hipMemset(mbar, 0, sizeof(MBar)));
+    unsigned mgen0 = 0;
+    auto run_m = [&](auto kern) {
+        hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), 0, st, p, mbar, steps, mgen0);
+        mgen0 += 3u * (unsigned)steps;
+    };
+    const float t_mbar = timeit("member barriers only (fenced)", [&] { run_m(k_persist_m<false, false, true>); });
+    const float t_mbar0 = timeit("member barriers only (no fence)", [&] { run_m(k_persist_m<false, false, false>); });
+    const float t_mp = timeit("persistent, member barriers", [&] { run_m(k_persist_m<false, true, true>); });
+    const float t_mpp = timeit("persistent + prefetch, member", [&] { run_m(k_persist_m<true, true, true>); });
+    const float t_mpp0 = timeit("  the same, fences removed", [&] { run_m(k_persist_m<true, true, false>); });
+    MBar hm; CK(hipMemcpy(&hm, mbar, sizeof hm, hipMemcpyDeviceToHost));
+    printf("member barrier: %.2f us each fenced, %.2f without fences; persistent / graph = %.3f, with prefetch %.3f (no fences: %.3f); error flag %u\n",
+           1e3 * t_mbar / (3.0 * steps), 1e3 * t_mbar0 / (3.0 * steps), t_mp / t_graph, t_mpp / t_graph, t_mpp0 / t_graph, hm.err[0]);
     CK(hipMemcpy(&hb, bar, sizeof hb, hipMemcpyDeviceToHost));
     printf("barrier: %.2f us each; persistent / graph = %.3f, with prefetch %.3f; barrier error flag %u\n", 1e3 * t_bar / (3.0 * steps), t_p / t_graph,
            t_pp / t_graph, hb.err[0]);
-    return hb.err[0] ? 2 : 0;
+    return (hb.err[0] || hm.err[0]) ? 2 : 0;
 }
