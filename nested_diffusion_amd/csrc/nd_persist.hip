@@ -17,8 +17,9 @@
 // an `sc1` load (L1 bypassed, L2-served); each storing wave drains (s_waitcnt vmcnt(0)), the workgroup meets at its own barrier, ONE
 // lane adds to the member's arrival counter (agent-scope atomic), one lane polls that counter (sc1 loads, s_sleep between), the
 // workgroup barrier again, then the loads.  No release / acquire fence (each costs 1.7 us and a whole-L2 write-back or an L1 flush).
-// Counters are zeroed by a memset node in front of every launch; every spin is bounded: a wait that exceeds `spin_ticks` sets the
-// sticky error word, and the workgroup (and, through that word, every other one) leaves the kernel -- nd_persist_status reports it.
+// The barriers are sense-reversing and leave their counters clean, so a launch needs no reset; every spin is bounded: a wait that exceeds
+// `spin_ticks` sets the sticky error word, and the workgroup (and, through that word, every other one) leaves the kernel --
+// nd_persist_status reports it (and, asked to, clears the whole barrier block: an abandoned launch leaves counters behind).
 // All workgroups of the grid must be resident at once: grid <= CU count, one workgroup per CU (by its LDS request), one process per
 // device (the deployment the multi-GPU path has anyway; ND_PERSIST=0 selects the graph form for rehearsals that share a device).
 #include "nd_persist.hpp"
@@ -65,19 +66,31 @@ __device__ __forceinline__ void ps_st16_sc1(__amdgpu_buffer_rsrc_t r, int voff, 
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, 16);
 }
 
-// Per-member barrier.  `target` = arrivals that complete it (barrier index within the launch x workgroups of the member).
+// Per-member barrier, sense-reversing, self-cleaning: `count` is 0 between barriers (the last arriver zeroes it BEFORE it publishes the
+// next generation), `gen` only ever grows.  A workgroup reads the generation once at kernel start (it cannot move before this workgroup
+// has arrived at the member's first barrier) and counts its own barriers from there, so a launch needs NO host-side reset: a memset
+// node in front of the kernel node was tried first and is not ordered against the kernel on every replay path of ROCm 7.2's graph
+// executor (replays enqueued back to back behind a device synchronise started with the previous launch's counter values: every
+// barrier passed at once and all results were wrong -- tools/persist_check.py, profiles/r06_persistent_loop_experiment.txt).
 // Returns false when the wait was abandoned (error word set, here or by another workgroup): the caller leaves the kernel.
-__device__ __forceinline__ bool ps_member_barrier(unsigned* counter, unsigned* errw, unsigned target, int spin_ticks, unsigned* s_flag) {
+__device__ __forceinline__ bool ps_member_barrier(unsigned* count, unsigned* gen, unsigned* errw, unsigned my_gen, unsigned wpm, int spin_ticks,
+                                                  unsigned* s_flag) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // EVERY storing wave drains its write-through stores
     __syncthreads();
     if (threadIdx.x == 0) {
-        __hip_atomic_fetch_add((nd_gu32)counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const long long t0 = wall_clock64();
+        const unsigned old = __hip_atomic_fetch_add((nd_gu32)count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         unsigned ok = 1u;
-        while (ps_ld_sc1(counter) < target) {
-            __builtin_amdgcn_s_sleep(2);
-            if (ps_ld_sc1(errw) != 0u) { ok = 0u; break; }
-            if (wall_clock64() - t0 > (long long)spin_ticks) { ps_st_sc1(errw, 1u); ok = 0u; break; }
+        if (old + 1u == wpm) {                                // last arriver: clean the counter, then open the barrier
+            ps_st_sc1(count, 0u);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_fetch_add((nd_gu32)gen, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            const long long t0 = wall_clock64();
+            while ((int)(ps_ld_sc1(gen) - my_gen) < 0) {      // (wrap-safe: generations are compared by their difference)
+                __builtin_amdgcn_s_sleep(2);
+                if (ps_ld_sc1(errw) != 0u) { ok = 0u; break; }
+                if (wall_clock64() - t0 > (long long)spin_ticks) { ps_st_sc1(errw, 1u); ok = 0u; break; }
+            }
         }
         *s_flag = ok;
     }
@@ -134,10 +147,14 @@ __global__ __launch_bounds__(PS_WAVES * 64) void k_persist_loop(PersistArgs args
     const int base = nfr / wpm, rem = nfr - base * wpm;
     const int nact = base + (j < rem ? 1 : 0);
     const int fi0 = j * base + min(j, rem);
-    unsigned* const counter = bar + g * 32;
+    unsigned* const counter = bar + g * 32;               // arrival counter and generation word of this member, 64 bytes apart
+    unsigned* const genw = bar + g * 32 + 16;
     unsigned* const errw = bar + ND_PERSIST_ERR_WORD;
     unsigned* const s_flag = reinterpret_cast<unsigned*>(smem + L::flag);
-    unsigned bar_n = 0;                                   // barriers this workgroup has passed
+    if (tid == 0) *s_flag = ps_ld_sc1(genw);              // the member's generation as this launch finds it (see ps_member_barrier)
+    __syncthreads();
+    unsigned bar_gen = *s_flag;                           // generation that completes this workgroup's NEXT barrier, minus one
+    __syncthreads();
 #ifdef ND_PERSIST_TIMING
     long long ps_acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, ps_last = 0;
 #endif
@@ -236,7 +253,7 @@ __global__ __launch_bounds__(PS_WAVES * 64) void k_persist_loop(PersistArgs args
             };
             auto G = [&](int i) { return min(wave + i * WAVES, glast); };
             if (ngw > 0) LDW(wA, G(0));                           // weights of the first stage: in flight across the barrier
-            alive = ps_member_barrier(counter, errw, ++bar_n * (unsigned)wpm, spin_ticks, s_flag);
+            alive = ps_member_barrier(counter, genw, errw, ++bar_gen, (unsigned)wpm, spin_ticks, s_flag);
             if (!alive) return;
             PS_STAMP(MODE == 0 ? 2 : 5);
             if (ngw > 0) LDX(xA, G(0));
@@ -431,7 +448,7 @@ __global__ __launch_bounds__(PS_WAVES * 64) void k_persist_loop(PersistArgs args
         PS_STAMP(1);
         if (!layer(std::integral_constant<int, 0>{}, t)) return;
         if (!layer(std::integral_constant<int, 1>{}, t)) return;
-        if (!ps_member_barrier(counter, errw, ++bar_n * (unsigned)wpm, spin_ticks, s_flag)) return;
+        if (!ps_member_barrier(counter, genw, errw, ++bar_gen, (unsigned)wpm, spin_ticks, s_flag)) return;
         PS_STAMP(8);
     }
 #ifdef ND_PERSIST_TIMING

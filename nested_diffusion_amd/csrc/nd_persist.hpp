@@ -6,11 +6,10 @@
 #include "nd_common.hpp"
 #include "nd_step.hpp"
 
-// Barrier block in the handle's workspace: word g*32 = arrival counter of the launch's g-th member (each on a 128-byte line of its
-// own); the first ND_PERSIST_BAR_ZERO_BYTES are zeroed by a memset node in front of EVERY launch (epochs are counted within a launch);
-// word ND_INLINE_DESCS*32 = sticky error word (a barrier wait gave up), cleared only by nd_bind_workspace / nd_persist_status(reset).
+// Barrier block in the handle's workspace: words g*32 and g*32 + 16 = arrival counter and generation of the launch's g-th member (a
+// 128-byte line per member); word ND_INLINE_DESCS*32 = sticky error word (a barrier wait gave up).  Zeroed by nd_bind_workspace and by
+// nd_persist_status(reset); never by a launch (the barriers clean up after themselves, csrc/nd_persist.hip).
 #define ND_PERSIST_BAR_WORDS ((ND_INLINE_DESCS + 1) * 32)
-#define ND_PERSIST_BAR_ZERO_BYTES (ND_INLINE_DESCS * 32 * 4)
 #define ND_PERSIST_ERR_WORD (ND_INLINE_DESCS * 32)
 
 struct PersistScalars {

@@ -824,7 +824,7 @@ extern "C" int nd_persist_status(nd_handle h, int reset) {
     HIP_CHECK(hipDeviceSynchronize());
     unsigned flag = 0;
     HIP_CHECK(hipMemcpy(&flag, h->persist_bar + ND_PERSIST_ERR_WORD, sizeof flag, hipMemcpyDeviceToHost));
-    if (reset && flag) HIP_CHECK(hipMemset(h->persist_bar + ND_PERSIST_ERR_WORD, 0, sizeof flag));
+    if (reset && flag) HIP_CHECK(hipMemset(h->persist_bar, 0, ND_PERSIST_BAR_WORDS * sizeof(unsigned)));   // counters of the abandoned launch too
     return flag ? 1 : 0;
 }
 
@@ -975,18 +975,6 @@ struct Emitter {
             last = node;
         }
     }
-    void memset32(void* dst, size_t bytes) {           // zero `bytes` (a multiple of 4) at dst
-        if (err != hipSuccess) return;
-        if (!graph) {
-            err = hipMemsetAsync(dst, 0, bytes, st);     // eager, or recorded by the stream capture
-        } else {
-            hipMemsetParams p{};
-            p.dst = dst; p.elementSize = 4; p.width = bytes / 4; p.height = 1; p.pitch = bytes; p.value = 0;
-            hipGraphNode_t node;
-            err = hipGraphAddMemsetNode(&node, graph, last ? &last : nullptr, last ? 1 : 0, &p);
-            last = node;
-        }
-    }
     void emit(void* fn, dim3 grid, dim3 block, void** args, size_t lds = 0) {
         if (err != hipSuccess) return;
         if (!graph) {
@@ -1017,7 +1005,7 @@ static hipError_t emit_loop(nd_handle_s* h, Emitter& em, int m0, int nm, StepIO 
         i2.d[g] = h->descs_host[(size_t)L_LIN2 * K + m0 + g];
         i3.d[g] = h->descs_host[(size_t)L_LIN3 * K + m0 + g];
     }
-    // ONE launch for the whole loop where the plan allows (csrc/nd_persist.hip): [zero the arrival counters] -> k_persist_loop
+    // ONE launch for the whole loop where the plan allows (csrc/nd_persist.hip)
     h->persist_last = false;
     if (h->persist_mode && inl) {
         const PersistPlan pp = nd_persist_plan(F, M, nm, C, h->half);
@@ -1040,7 +1028,6 @@ static hipError_t emit_loop(nd_handle_s* h, Emitter& em, int m0, int nm, StepIO 
                 }
                 ev = h->probe_events.data();
             }
-            em.memset32(h->persist_bar, ND_PERSIST_BAR_ZERO_BYTES);
             if (ev) em.record(ev[0]);
             void* ap[] = {&pa};
             em.emit(pp.fn, pp.grid, pp.block, ap, pp.lds);

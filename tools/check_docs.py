@@ -1,6 +1,6 @@
 """Do the documents still say what the committed evidence says?   python tools/check_docs.py   (exit 1 and a list on any mismatch)
 
-Figures quoted in profiles/README.md and DESIGN.md carry an invisible tag right behind them naming the file they come from:
+Figures quoted in profiles/README.md, DESIGN.md and EXPERIMENTS.md carry an invisible tag right behind them naming the file they come from:
     <!--chk csv=r05_kernel_stats_bench.csv name="k_skinny<2, 6, 4, 2, 0," avg_us=58.8-->   mean duration of the CSV row whose Name contains `name`
     <!--chk csv=... name="..." calls=1600-->                                                  its call count
     <!--chk log=r05_gpu_suite.log passed=206-->                                               pytest's "N passed" line
@@ -16,6 +16,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PROF = os.path.join(ROOT, "profiles")
+DOCS = ("profiles/README.md", "DESIGN.md", "EXPERIMENTS.md")      # the documents whose tagged figures are checked (and --fix rewrites)
 TAG = re.compile(r"<!--chk\s+(.*?)-->")
 KV = re.compile(r'(\w+)=("([^"]*)"|\S+)')
 
@@ -80,7 +81,7 @@ def fix() -> int:
     """--fix: rewrite every tagged figure (the number right in front of its tag, and the tag's own copy) from the file the tag names, at
     the digits the tag shows.  For re-profiled rounds: the prose around the figures is the author's business, the figures are the files'."""
     n = 0
-    for doc in ("profiles/README.md", "DESIGN.md"):
+    for doc in DOCS:
         path = os.path.join(ROOT, doc)
         text = open(path).read()
 
@@ -111,7 +112,7 @@ def main() -> int:
     if "--fix" in sys.argv[1:]:
         return fix()
     problems, n_tags = [], 0
-    for doc in ("profiles/README.md", "DESIGN.md"):
+    for doc in DOCS:
         text = open(os.path.join(ROOT, doc)).read()
         for m in TAG.finditer(text):
             args = {k: (q if q is not None and v.startswith('"') else v) for k, v, q in KV.findall(m.group(1))}
@@ -135,6 +136,9 @@ def main() -> int:
     first = first[:first.index("\n## round", 8)] if "\n## round" in first[8:] else first
     if f"`{newest}_kernel_stats_bench.csv`" not in first or f"## round {rounds[-1]} " not in first[:40] + " ":
         problems.append(f"profiles/README.md: the first section is not round {rounds[-1]} or does not list {newest}_kernel_stats_bench.csv")
+    n_design = len(design.splitlines())
+    if n_design > 420:
+        problems.append(f"DESIGN.md has grown to {n_design} lines: measured-and-removed material belongs in EXPERIMENTS.md")
     if n_tags < 8:
         problems.append(f"only {n_tags} <!--chk ...--> tags found: the quoted figures are no longer tied to their files")
     header = open(os.path.join(ROOT, "include", "nested_diffusion.h")).read()
