@@ -310,7 +310,7 @@ def main():
     host_in = None
     if rank == 0 and world == 1:
         host_images = images.cpu()
-        n_h = max(1, min(args.steps, 20))
+        n_h = max(1, min(args.steps, 50))
         tgt = torch.zeros(B, dtype=torch.int64)
 
         def host_loop(n):

@@ -181,6 +181,14 @@ __global__ __launch_bounds__(PS_WAVES * 64) void k_persist_loop(PersistArgs args
     const int glast = ngroups > 0 ? ngroups - 1 : 0;
     float (*const red)[NF * MT * 256] = reinterpret_cast<float (*)[NF * MT * 256]>(smem + L::red);
 
+    // A wait that was given up (the grid was not resident at once): the member's y_0 rows become NaNs, so no caller can mistake the
+    // previous call's contents of the output buffer for a result; nd_persist_status reports the cause.
+    auto poison = [&]() {
+        if (j != 0) return;
+        const StepIO io = PS_ARG(ka, StepIO, io);
+        for (int p = tid; p < pairs; p += WAVES * 64) ND_GW(io.y0_out)[g * io.y0_ms + p] = __builtin_nanf("");
+    };
+
     // ONE ConditionalLinear block of this workgroup's fragments (k_skinny's main loop and epilogue, MODE 0 / 1), entered through the
     // member's barrier: the first register stage of W and the epilogue's table entries do not depend on other workgroups and are
     // requested BEFORE the wait.  x: the frag16 activations the block reads (h1 / h2), out: h2 (MODE 0) or the eps partials (MODE 1).
@@ -446,9 +454,9 @@ __global__ __launch_bounds__(PS_WAVES * 64) void k_persist_loop(PersistArgs args
             }
         }
         PS_STAMP(1);
-        if (!layer(std::integral_constant<int, 0>{}, t)) return;
-        if (!layer(std::integral_constant<int, 1>{}, t)) return;
-        if (!ps_member_barrier(counter, genw, errw, ++bar_gen, (unsigned)wpm, spin_ticks, s_flag)) return;
+        if (!layer(std::integral_constant<int, 0>{}, t)) { poison(); return; }
+        if (!layer(std::integral_constant<int, 1>{}, t)) { poison(); return; }
+        if (!ps_member_barrier(counter, genw, errw, ++bar_gen, (unsigned)wpm, spin_ticks, s_flag)) { poison(); return; }
         PS_STAMP(8);
     }
 #ifdef ND_PERSIST_TIMING

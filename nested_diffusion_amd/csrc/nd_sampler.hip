@@ -1015,7 +1015,8 @@ static hipError_t emit_loop(nd_handle_s* h, Emitter& em, int m0, int nm, StepIO 
             for (int g = 0; g < nm; ++g) { pa.l2[g] = i2.d[g]; pa.l3[g] = i3.d[g]; pa.mem[g] = mi.m[g]; }
             pa.io = io;
             const char* act = getenv("ND_PERSIST_ACTIVE");                  // experiments only: run the first n members of the launch
-            pa.s = PersistScalars{h->persist_bar, nm, B, M, maxM, F, T, h->persist_skew_ticks, 100000000 /* 1 s of the 100 MHz clock */,
+            const char* spin = getenv("ND_PERSIST_SPIN_TICKS");             // tests only: how long a barrier wait may last (100 MHz ticks)
+            pa.s = PersistScalars{h->persist_bar, nm, B, M, maxM, F, T, h->persist_skew_ticks, spin ? atoi(spin) : 100000000 /* 1 s */,
                                   act ? atoi(act) : nm};
             note_h_layout(h, m0, nm, false);
             hipEvent_t* ev = nullptr;

@@ -124,8 +124,9 @@ def get_test_loader(args, config, shard=None):
         return SyntheticLoader(n, B, config.data.num_classes, seed=getattr(args, "seed", 0) or 0, size=size, shard=shard)
     ds = get_dataset(args, config)
     lo, hi = shard if shard is not None else (0, B)
+    # pinned batches: the runner uploads them with a non-blocking copy on a side stream (runner._rank_batches) without a staging copy
     loader = torch.utils.data.DataLoader(ds, batch_sampler=ShardBatchSampler(len(ds), B, lo, hi),
-                                         num_workers=int(getattr(config.data, "num_workers", 0) or 0))
+                                         num_workers=int(getattr(config.data, "num_workers", 0) or 0), pin_memory=torch.cuda.is_available())
     loader.shard = (lo, hi) if shard is not None else None
     loader.global_batch = B
     return loader

@@ -162,6 +162,12 @@ def main(argv=None) -> int:
     if args.seed is None:
         args.seed = random.randint(0, 10000)                      # main.py:163-164
     args.doc = args.doc + "/split_" + str(args.split)             # main.py:384
+    # --thread (main.py:40; parsed by the reference and never used, quirk Q10; test.sh passes 8): the host-side torch work here is
+    # decode, staging copies and tiny tensors -- on a box that shows hundreds of logical CPUs under a container quota torch's default
+    # (all of them) makes a 19 MB copy take 20-60 ms instead of 2, so the flag bounds the intra-op threads of this process
+    if getattr(args, "thread", 0) and args.thread > 0:
+        import torch
+        torch.set_num_threads(int(args.thread))
     from . import dist as nd_dist
     _, _, world = nd_dist.init_from_env()
     failed = False

@@ -202,7 +202,8 @@ class Diffusion(object):
         main = torch.cuda.current_stream(self.device)
         side = torch.cuda.Stream(self.device)
         sharded = getattr(test_loader, "shard", None) == (lo, hi)
-        pins, bufs, evs = [None, None], [None, None], [None, None]
+        pins, bufs, evs, held = [None, None], [None, None], [None, None], [None, None]
+        tpins, tbufs = [None, None], [None, None]
 
         def stage(k, item):
             images_raw, target = item
@@ -212,19 +213,38 @@ class Diffusion(object):
                 raise ValueError(f"loader handed {x.shape[0]} rows for the shard [{lo}, {hi})")
             if x.is_cuda:                                   # a caller's loader that already lives on the device
                 return x.to(self.device, torch.float32), t.to(self.device), None
-            if pins[k] is None or pins[k].shape != x.shape:
-                pins[k] = torch.empty(x.shape, dtype=torch.float32, pin_memory=True)
+            if bufs[k] is None or bufs[k].shape != x.shape:
                 bufs[k] = torch.empty(x.shape, dtype=torch.float32, device=self.device)
             if evs[k] is not None:
                 evs[k].synchronize()                        # the copy that last read this staging buffer (two batches ago)
-            pins[k].copy_(x)
+            if x.dtype == torch.float32 and x.is_pinned():  # a loader with pin_memory=True: nothing to stage
+                src = x
+            else:
+                if pins[k] is None or pins[k].shape != x.shape:
+                    pins[k] = torch.empty(x.shape, dtype=torch.float32, pin_memory=True)
+                if x.dtype == torch.float32 and x.is_contiguous():
+                    # one memcpy on this thread.  (Tensor.copy_ spreads a 19 MB copy over every logical CPU the box shows; under a
+                    # container's CPU quota that takes 20-60 ms instead of 2 -- measured: bench.py's pcie_inclusive leg)
+                    import numpy as np
+                    np.copyto(pins[k].numpy(), x.numpy())
+                else:
+                    pins[k].copy_(x)
+                src = pins[k]
+            # the targets ride along (pinned too: a pageable H2D copy on the compute stream would hold the HOST until batch n - 1 has
+            # finished, and the launches behind it would start late)
+            if tpins[k] is None or tpins[k].shape != t.shape or tpins[k].dtype != t.dtype:
+                tpins[k] = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+                tbufs[k] = torch.empty(t.shape, dtype=t.dtype, device=self.device)
+            tpins[k].copy_(t)
             side.wait_stream(main)                          # bufs[k]'s last reader (batch n - 1, already enqueued) before it is overwritten
             with torch.cuda.stream(side):
-                bufs[k].copy_(pins[k], non_blocking=True)
+                bufs[k].copy_(src, non_blocking=True)
+                tbufs[k].copy_(tpins[k], non_blocking=True)
                 evs[k] = torch.cuda.Event()
                 evs[k].record(side)
             self.bytes_uploaded += x.numel() * 4
-            return bufs[k], t.to(self.device, non_blocking=True), evs[k]
+            held[k] = src                                   # a caller's pinned batch stays alive until its copy has been waited for
+            return bufs[k], tbufs[k], evs[k]
 
         it = iter(test_loader)
         nxt = None
@@ -344,6 +364,8 @@ class Diffusion(object):
             n_step_img += B * len(self.members) * self.mc_trials * self.num_timesteps
         torch.cuda.synchronize(self.device)
         dt = time.time() - t0
+        if self.engine.loop_form() == "one_launch":
+            self.engine.persist_status()                                     # raises if a barrier wait of the one-launch loop was abandoned
         rep = ops.report(torch.cat(piw_mc), torch.cat(var_mc), torch.cat(prob_mc), torch.cat(mv_class), torch.cat(target_class),
                          self.temperature, n_bins=10)                        # :801-815
         acc = rep["accuracy"]
