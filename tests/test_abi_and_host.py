@@ -58,6 +58,15 @@ def test_abi_argument_validation_without_gpu():
     assert 13e9 < nbytes < 17e9, nbytes
     assert lib.nd_create(ctypes.byref(good), ctypes.byref(h)) == 0
     assert lib.nd_encode(h, 0, 1, None, 4, None) != 0              # workspace not bound
+    # form of the T-step loop (host state only here): 0 = per-step kernel nodes, 1 = one launch; nothing else; a fresh handle reports
+    # the graph form, and the status query needs a bound workspace
+    assert lib.nd_loop_form(h) == 0
+    assert lib.nd_set_loop_form(h, 1, ctypes.c_float(12.5)) == 0 and lib.nd_set_loop_form(h, 0, ctypes.c_float(-1.0)) == 0
+    assert lib.nd_set_loop_form(h, 2, ctypes.c_float(0.0)) != 0 and b"mode" in lib.nd_last_error()
+    assert lib.nd_set_loop_form(h, 1, ctypes.c_float(2e6)) != 0 and lib.nd_set_loop_form(None, 1, ctypes.c_float(0.0)) != 0
+    assert lib.nd_persist_status(h, 0) < 0 and b"workspace" in lib.nd_last_error()
+    assert lib.nd_skinny_row_fragments(32) == 2 and lib.nd_skinny_row_fragments(70) == 5 and lib.nd_skinny_row_fragments(64) == 4
+    assert lib.nd_skinny_row_fragments(16) == 1 and lib.nd_skinny_row_fragments(0) < 0
     assert lib.nd_destroy(h) == 0
     assert lib.nd_linear(None, None, None, None, None, 1, 16, 1, 0, 0, None, 0, None) != 0
     assert lib.nd_packed_bytes(3, 32, 0) == 16 * 32 * 4            # rows padded to 16

@@ -189,3 +189,43 @@ def test_perturbations_of_image_i_do_not_depend_on_the_world_size(world, monkeyp
                 assert got == ref[lo:hi] and len(got) == hi - lo
     with pytest.raises(ValueError):
         Diffusion.perturb(fake, torch.zeros(3, 3, H, H), 2, 6, B)                    # 3 rows handed for a shard of 4
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_disk_loader_decodes_only_the_ranks_files(tmp_path, world, monkeypatch):
+    """data.get_test_loader(shard=(lo, hi)) over an image tree on disk (ImageFolder ordering + the reference's transforms,
+    dataset_helper/chest_x_ray_dataset.py:28-51): rank r's loader yields rows [lo, hi) of every global batch with their targets, opens
+    exactly those files, and the ranks' pieces concatenated in rank order are the unsharded loader's batches (drop_last on the GLOBAL
+    batch: 7 images, batch 3 -> two batches)."""
+    import argparse
+    import numpy as np
+    from PIL import Image
+    import nested_diffusion_amd.data as data
+    from nested_diffusion_amd import dist as nd_dist
+    rng = np.random.default_rng(0)
+    names = {"NORMAL": ["a.png", "b.png", "c.png", "d.png"], "PNEUMONIA": ["e.png", "f.png", "g.png"]}
+    for cls, files in names.items():
+        os.makedirs(os.path.join(str(tmp_path), "testing", cls))
+        for f in files:
+            Image.fromarray(rng.integers(0, 256, size=(40, 40, 3), dtype=np.uint8), "RGB").save(os.path.join(str(tmp_path), "testing", cls, f))
+    ns = argparse.Namespace
+    args = ns(synthetic_batches=0, preprocess="grayscaled", seed=0)
+    cfg = ns(data=ns(dataset="ChestXRay", dataroot=str(tmp_path), num_classes=2, num_workers=0), model=ns(data_dim=3 * 224 * 224), testing=ns(batch_size=3))
+    opened = []
+    orig = data.ImageFolderDataset.__getitem__
+    monkeypatch.setattr(data.ImageFolderDataset, "__getitem__", lambda self, i: (opened.append(i), orig(self, i))[1])
+    full = list(data.get_test_loader(args, cfg))
+    assert len(full) == 2 and opened == [0, 1, 2, 3, 4, 5] and torch.cat([t for _, t in full]).tolist() == [0, 0, 0, 0, 1, 1]
+    pieces = [[], []]
+    for r in range(world):
+        lo, hi = nd_dist.shard_bounds(3, r, world)
+        opened.clear()
+        loader = data.get_test_loader(args, cfg, shard=(lo, hi))
+        assert loader.shard == (lo, hi) and loader.global_batch == 3
+        got = list(loader)
+        assert opened == [b * 3 + i for b in range(2) for i in range(lo, hi)]
+        for b, (x, t) in enumerate(got):
+            assert tuple(x.shape) == (hi - lo, 3, 224, 224)
+            pieces[b].append((x, t))
+    for b in range(2):
+        assert torch.equal(torch.cat([x for x, _ in pieces[b]]), full[b][0]) and torch.equal(torch.cat([t for _, t in pieces[b]]), full[b][1])
