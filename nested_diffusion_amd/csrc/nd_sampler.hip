@@ -34,7 +34,7 @@ extern "C" int nd_debug_set_wg_times(void* dev_ptr) {     // the k_skinny instan
     return (nd_debug_set_wg_times_m0(dev_ptr) | nd_debug_set_wg_times_m1(dev_ptr) | nd_debug_set_wg_times_m2(dev_ptr)) ? -1 : 0;
 }
 #endif
-extern "C" const char* nd_version(void) { return "libnd_hip gfx950 f32 (f32-input MFMA streams + bf16x9 exact-product GEMMs and attention) r5"; }
+extern "C" const char* nd_version(void) { return "libnd_hip gfx950 f32 (f32-input MFMA streams + bf16x9 exact-product GEMMs and attention) r6"; }
 int nd_set_err(int code, const char* fmt, ...) {
     char buf[512];
     va_list ap;

@@ -5,7 +5,8 @@ Variants, all K = 5, T = 100, B = 32 at config dims, same process:
   B  + a device-to-device copy of the batch into that buffer per step
   C  B + an independent pinned H2D copy of 19.3 MB on a side stream per step (no dependency: pure overlap cost)
   D  the runner's loader loop (runner._rank_batches: staging memcpy, side-stream H2D one batch ahead, event wait)
-  E  D with the batches already pinned (no staging memcpy)"""
+  E  D with the batches already pinned (no staging memcpy)
+  F / G / H  the synchronisation pieces of D one at a time (see the functions)"""
 import argparse, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -64,5 +65,40 @@ def E(n):
         runner.predict_batch(x, clone=False)
 
 
+def F(n):                     # C + the compute stream waits for the side-stream copy (dependency, no write-after-read wait)
+    main = torch.cuda.current_stream(dev)
+    for _ in range(n):
+        with torch.cuda.stream(side):
+            sink.copy_(pinned, non_blocking=True)
+            ev = torch.cuda.Event(); ev.record(side)
+        main.wait_event(ev)
+        runner.predict_batch(other, clone=False)
+
+
+def G(n):                     # F + the side stream first waits for everything enqueued on the compute stream
+    main = torch.cuda.current_stream(dev)
+    for _ in range(n):
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            sink.copy_(pinned, non_blocking=True)
+            ev = torch.cuda.Event(); ev.record(side)
+        main.wait_event(ev)
+        runner.predict_batch(other, clone=False)
+
+
+def H(n):                     # G, but the copy of the NEXT batch is enqueued before this batch's launch (the loader loop's order)
+    main = torch.cuda.current_stream(dev)
+    ev = None
+    for _ in range(n):
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            sink.copy_(pinned, non_blocking=True)
+            ev_next = torch.cuda.Event(); ev_next.record(side)
+        if ev is not None:
+            main.wait_event(ev)
+        runner.predict_batch(other, clone=False)
+        ev = ev_next
+
+
 for rnd in range(2):
-    print(f"round {rnd}: " + "  ".join(f"{name} {timeit(fn, a.steps):.3f} ms" for name, fn in (("A", A), ("B", Bv), ("C", C), ("D", D), ("E", E))))
+    print(f"round {rnd}: " + "  ".join(f"{name} {timeit(fn, a.steps):.3f} ms" for name, fn in (("A", A), ("B", Bv), ("C", C), ("D", D), ("E", E), ("F", F), ("G", G), ("H", H))))
