@@ -100,5 +100,33 @@ def H(n):                     # G, but the copy of the NEXT batch is enqueued be
         ev = ev_next
 
 
+def I(n):                     # F + an event recorded on the compute stream per batch (the marker a write-after-read guard needs), nobody waits on it
+    main = torch.cuda.current_stream(dev)
+    for _ in range(n):
+        with torch.cuda.stream(side):
+            sink.copy_(pinned, non_blocking=True)
+            ev = torch.cuda.Event(); ev.record(side)
+        main.wait_event(ev)
+        runner.predict_batch(other, clone=False)
+        main.record_event()
+
+
+def J(n):                     # H with THREE buffers: the guard waits for the launch three batches back (long finished), so the copy starts when it is enqueued
+    main = torch.cuda.current_stream(dev)
+    done, ev = [None, None, None], None
+    for i in range(n):
+        k = i % 3
+        if done[k] is not None:
+            side.wait_event(done[k])
+        with torch.cuda.stream(side):
+            sink.copy_(pinned, non_blocking=True)
+            ev_next = torch.cuda.Event(); ev_next.record(side)
+        if ev is not None:
+            main.wait_event(ev)
+        runner.predict_batch(other, clone=False)
+        done[(i - 1) % 3] = main.record_event()
+        ev = ev_next
+
+
 for rnd in range(2):
-    print(f"round {rnd}: " + "  ".join(f"{name} {timeit(fn, a.steps):.3f} ms" for name, fn in (("A", A), ("B", Bv), ("C", C), ("D", D), ("E", E), ("F", F), ("G", G), ("H", H))))
+    print(f"round {rnd}: " + "  ".join(f"{name} {timeit(fn, a.steps):.3f} ms" for name, fn in (("A", A), ("B", Bv), ("C", C), ("D", D), ("E", E), ("F", F), ("G", G), ("H", H), ("I", I), ("J", J))))
