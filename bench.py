@@ -309,7 +309,7 @@ def main():
     # ahead so that batch n + 1's 19.3 MB cross PCIe under batch n's graph.  Reported beside `value`, never as `value` (rank 0, N = 1).
     host_in = None
     if rank == 0 and world == 1:
-        host_images = images.cpu()
+        host_images = images.cpu().pin_memory()          # as the runner's DataLoader(pin_memory=True) hands batches over
         n_h = max(1, min(args.steps, 50))
         tgt = torch.zeros(B, dtype=torch.int64)
 
@@ -418,8 +418,8 @@ def main():
         "unprobed_ms_per_step": 1e3 * dt_unprobed / args.steps,
         "unprobed_value": world * units * args.steps / dt_unprobed,
         "pcie_inclusive": ({"ms_per_step": 1e3 * host_in, "value": units / host_in,
-                            "note": "every batch handed over as a host tensor through the runner's loader loop (pinned staging, side-stream H2D one batch "
-                                    "ahead), transfers inside the timing; not the headline"}
+                            "note": "every batch handed over as a pinned host tensor through the runner's loader loop (side-stream H2D one batch ahead, "
+                                    "event wait, device-to-device copy into the library's input buffer), transfers inside the timing; not the headline"}
                            if host_in else None),
         "stages_ms": stages,
         "sampler_only_value": units / (stages["sampler_ms"] * 1e-3),

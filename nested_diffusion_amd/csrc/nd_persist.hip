@@ -1,16 +1,19 @@
 // nd_persist.hip -- a whole p_sample_loop (diffusion/diffusion_utils.py:133-163) as ONE kernel launch.  gfx950 only.
 //
 // The hipGraph form of the loop (csrc/nd_sampler.hip) is 3T+1 kernel nodes: head, lin2 block, lin3 + lin4 block per step, all
-// members in every launch.  Every launch boundary is a chip-wide barrier: the ramp of 255 workgroups asking for their first register
-// stage at once, the cross-wave epilogue, the launch gap and the whole latency-bound step head are times at which NO workgroup
-// streams weights -- about 20 us of a 122 us step at K = 5, M = 32, F = 4096 -- although the members' chains are independent.
+// members in every launch.  This is the same loop with no launch boundary: each member's ~51 workgroups stay on their CUs for all T
+// steps and meet only each other, at a per-member barrier after each of the three phases of a step (head | lin2 | lin3 + lin4);
+// members may be started `skew` apart.  The arithmetic is k_skinny's and k_step_head's, instruction for instruction where it
+// matters: the same fragment dealing (a workgroup owns the same 5 or 6 weight fragments of lin2 AND lin3 as in the graph form), the
+// same per-wave interleaved K split, the same cross-wave sum order, the same reduction trees over the eps partials  =>  the same bits
+// as the graph form (tests/test_gpu_sampler.py asserts equality on every state of every chain).
 //
-// Here each member's ~51 workgroups run the T steps inside one launch and meet only each other, at a per-member barrier after each
-// of the three phases of a step (head | lin2 | lin3 + lin4), so the members drift apart (and are started `skew` apart on purpose):
-// while one member reduces its eps partials, the other four keep the HBM / fabric busy.  The arithmetic is k_skinny's and
-// k_step_head's, instruction for instruction where it matters: the same fragment dealing (a workgroup owns the same 5 or 6 weight
-// fragments of lin2 AND lin3 as in the graph form), the same per-wave interleaved K split, the same cross-wave sum order, the same
-// reduction trees over the eps partials  =>  the same bits as the graph form (tests/test_gpu_sampler.py asserts equality).
+// MEASURED (round 6, EXPERIMENTS.md #14, profiles/r06_persistent_loop_experiment.txt): 1.08 x the graph form's time at K = 5, M = 32,
+// F = 4096 -- the idea was that launch boundaries are chip-wide barriers at which no workgroup streams, and that a resident kernel
+// could also keep part of its weights on chip.  The per-phase clocks say otherwise: a workgroup's loop is bound by its OWN exact-f32
+// MFMAs (37 us for five fragments with the rest of the chip idle), the six-fragment workgroup of every member is the critical path
+// and its 50 partners wait for it whether the wait is a kernel boundary or a barrier.  The form is therefore OPT-IN
+// (nd_set_loop_form / ND_PERSIST=1); the default is the graph form.
 //
 // Hand-off between workgroups (MI355X_MICROARCH.md, inter-workgroup visibility; per-XCD L2s are not coherent, a CU's L1 is never
 // refreshed): every byte another workgroup reads (h1, h2, the eps partials) is stored WRITE-THROUGH (`sc1`) and every load of it is
