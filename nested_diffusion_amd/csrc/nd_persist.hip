@@ -20,6 +20,8 @@
 // an `sc1` load (L1 bypassed, L2-served); each storing wave drains (s_waitcnt vmcnt(0)), the workgroup meets at its own barrier, ONE
 // lane adds to the member's arrival counter (agent-scope atomic), one lane polls that counter (sc1 loads, s_sleep between), the
 // workgroup barrier again, then the loads.  No release / acquire fence (each costs 1.7 us and a whole-L2 write-back or an L1 flush).
+// (The guide lists this hand-off form as MEASURED behaviour of gfx950 / ROCm 7.2, not as an architectural guarantee; here it is
+// checked bit for bit against the graph form on every state of every chain over repeated replays -- one more reason the form is opt-in.)
 // The barriers are sense-reversing and leave their counters clean, so a launch needs no reset; every spin is bounded: a wait that exceeds
 // `spin_ticks` sets the sticky error word, and the workgroup (and, through that word, every other one) leaves the kernel --
 // nd_persist_status reports it (and, asked to, clears the whole barrier block: an abandoned launch leaves counters behind).
