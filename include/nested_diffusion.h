@@ -159,6 +159,14 @@ int nd_profile_read(nd_handle h, float *out_us, int *n_samples);
  * intervals are stamped on every replay and are not left over from the eager first call. */
 int nd_profile_probe_nodes(nd_handle h);
 
+/* Refilling the input buffer early.  flag: a 32-bit word in host memory the DEVICE can write (pinned / mapped host memory), or NULL to
+ * switch the signal off.  With a flag set, every nd_predict_batch call or graph replay stores 1, 2, 3, ... to it (the count of calls since
+ * this function was called) as soon as the last kernel that reads images_dev has run -- the im2col of the conditioner and the pack of the
+ * encoder hoist, about a quarter into the batch -- so a loader may write the NEXT batch into images_dev (classification_train_separately.py:
+ * 722, the .to(device) of the batch loop) while this batch's sampler is still running.  Synchronises the device; drops the recorded batch
+ * graphs. */
+int nd_set_input_flag(nd_handle h, uint32_t *flag_host_visible);
+
 /* FORM OF THE SAMPLING LOOP (diffusion_utils.py:145-157, the T iterations of p_sample_loop).  mode 0: 3T+1 kernel nodes of a
  * hipGraph (head, lin2 block, lin3 + lin4 block per step).  mode 1: ONE kernel launch for the whole loop where the shape allows
  * (csrc/nd_persist.hip: 17..32 rows per member, fp32 operands, <= 8 members whose weights exceed the Infinity Cache; any other call

@@ -103,6 +103,7 @@ SIGNATURES = {
     "nd_p_sample": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _vp]),
     "nd_sample": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "nd_set_profiling": (_i, [_vp, _i]),
+    "nd_set_input_flag": (_i, [_vp, _vp]),
     "nd_set_loop_form": (_i, [_vp, _i, C.c_float]),
     "nd_loop_form": (_i, [_vp]),
     "nd_persist_status": (_i, [_vp, _i]),

@@ -439,6 +439,8 @@ struct nd_handle_s {
     float* tile_ws = nullptr;              // k-slab accumulators of k_cond_gemm's split tail (large-M steps only)
     bool b9 = false;                       // the large-M step blocks run on the bf16 matrix pipe (frag32b3 copies of lin2 / lin3 exist)
     unsigned long long* rng_state = nullptr;   // {seed, batch counter | first image << 32} of the in-library noise (nd_seed)
+    unsigned* input_seq = nullptr;             // calls of nd_predict_batch whose inputs have been consumed (device counter behind input_flag)
+    unsigned* input_flag = nullptr;            // caller's host-visible word that receives that count (nd_set_input_flag), or null
     unsigned* persist_bar = nullptr;           // barrier block of the one-launch loop (nd_persist.hpp): per-member arrival counters + sticky error word
     int persist_mode = 0;                      // ND_PERSIST: 0 = per-step kernels (hipGraph form), 1 = one launch per p_sample_loop where nd_persist_plan allows
     int persist_skew_ticks = 0;                // ND_PERSIST_SKEW_US: start offset between consecutive members (100 MHz ticks)
@@ -489,6 +491,7 @@ static void carve(nd_handle_s* h, char* base, size_t* total) {
     h->omabs = cv.take<float>(T);
     h->rng_state = cv.take<unsigned long long>(2);
     h->persist_bar = cv.take<unsigned>(ND_PERSIST_BAR_WORDS);
+    h->input_seq = cv.take<unsigned>(1);
     h->noise_ws = cv.take<float>(K * T * mM * C);
     h->logits_ws = cv.take<float>(K * mB * C);
     h->xpack = cv.take<float>(pB * D);
@@ -591,6 +594,7 @@ extern "C" int nd_bind_workspace(nd_handle h, void* ws, size_t bytes) {
     for (auto& m : h->members) HIP_CHECK(hipMemset(m.e0, 0, (size_t)((char*)m.splitk - (char*)m.e0)));
     HIP_CHECK(hipMemset(h->rng_state, 0, 2 * sizeof(unsigned long long)));
     HIP_CHECK(hipMemset(h->persist_bar, 0, ND_PERSIST_BAR_WORDS * sizeof(unsigned)));
+    HIP_CHECK(hipMemset(h->input_seq, 0, sizeof(unsigned)));
     return ND_OK;
 }
 
@@ -744,7 +748,31 @@ static hipError_t launch_step_block(nd_handle_s* h, const SkinnyDesc* table, int
     return launch_skinny<MODE>(table, F, F, M, t, nm, h->half, st);
 }
 
+// "The inputs of this batch have been read": count the call on the device and publish the count to the caller's host-visible word
+// (system-scope store: the word lives in pinned host memory).  Enqueued by nd_predict_batch right behind the LAST kernel that reads
+// images_dev, so a loader may refill that buffer for the next batch while this batch's sampler is still running.
+__global__ void k_inputs_consumed(unsigned* seq, unsigned* flag) {
+    const unsigned v = *seq + 1u;
+    *seq = v;
+    __hip_atomic_store(flag, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+extern "C" int nd_set_input_flag(nd_handle h, uint32_t* flag_host_visible) {
+    if (!h || !h->ws) return nd_set_err(ND_ERR_STATE, "workspace not bound");
+    if ((uintptr_t)flag_host_visible & 3) return nd_set_err(ND_ERR_ARG, "flag must be 4-byte aligned");
+    HIP_CHECK(hipDeviceSynchronize());
+    HIP_CHECK(hipMemset(h->input_seq, 0, sizeof(unsigned)));
+    h->input_flag = flag_host_visible;
+    drop_graphs(h);
+    return ND_OK;
+}
+
+static int encode_impl(nd_handle h, int m0, int nm, const float* x_dev, int B, void* stream, bool signal_inputs);
 extern "C" int nd_encode(nd_handle h, int m0, int nm, const float* x_dev, int B, void* stream) {
+    return encode_impl(h, m0, nm, x_dev, B, stream, false);
+}
+
+static int encode_impl(nd_handle h, int m0, int nm, const float* x_dev, int B, void* stream, bool signal_inputs) {
     int rc = check_range(h, m0, nm);
     if (rc != ND_OK) return rc;
     if (!x_dev) return nd_set_err(ND_ERR_ARG, "x_dev is NULL");
@@ -753,6 +781,8 @@ extern "C" int nd_encode(nd_handle h, int m0, int nm, const float* x_dev, int B,
     const nd_config& c = h->cfg;
     const int K = c.n_members, H = c.hidden_dim, F = c.feature_dim, D = c.data_dim;
     launch_pack(x_dev, h->xpack, B, D, h->half, st);       // images -> frag16 once; every member reads the same batch
+    if (signal_inputs && h->input_flag)                    // nd_predict_batch: x_dev (= images_dev) is not read again by this call
+        hipLaunchKernelGGL(k_inputs_consumed, dim3(1), dim3(1), 0, st, h->input_seq, h->input_flag);
     if (h->enc_splitk) {
         const SkinnyLaunch L = nd_skinny_launch<2>(D, H, B, nm, h->half);
         HIP_CHECK(nd_launch_skinny(L, SkinnyDesc{}, h->spk_dev + m0, nm, B, 0, st));
@@ -1208,7 +1238,7 @@ static int batch_enqueue(nd_handle_s* h, nd_cond c, const float* images, const f
     const bool draw = noise == nullptr;
     int rc = nd_guiding_prediction_first(c, images, h->logits_ws, out->yhat, B, K, st);     // member k <- mapping MLP k, k < K
     if (rc != ND_OK) return rc;
-    rc = nd_encode(h, 0, K, images, B, st);
+    rc = encode_impl(h, 0, K, images, B, st, true);       // (the conditioner's im2col ran before: the pack here is the last reader of `images`)
     if (rc != ND_OK) return rc;
     StepIO io{};
     io.yhat = out->yhat;  io.yhat_ms = (size_t)B * C;

@@ -282,6 +282,26 @@ class EnsembleEngine:
             self._batch_static[key] = buf
         return buf
 
+    def enable_input_flag(self) -> None:
+        """Ask the library to publish, per predict_batch call, the moment its input buffer has been read (nd_set_input_flag): a pinned
+        host word receives the count of calls whose inputs are consumed -- about a quarter into the batch -- so a loader can refill
+        batch_buffers(...)['images'] for the next batch under this batch's sampler (runner._rank_batches)."""
+        if getattr(self, "_input_flag", None) is None:
+            self._input_flag = torch.zeros(1, dtype=torch.int32).pin_memory()
+            self._batch_calls = 0
+            check(self.lib.nd_set_input_flag(self.h, self._input_flag.data_ptr()), "nd_set_input_flag")
+
+    def inputs_consumed(self, timeout_s: float = 30.0) -> None:
+        """Block (host) until every predict_batch issued so far has read its input buffer.  No-op without enable_input_flag()."""
+        if getattr(self, "_input_flag", None) is None:
+            return
+        import time
+        t0 = time.perf_counter()
+        while int(self._input_flag[0]) < self._batch_calls:
+            if time.perf_counter() - t0 > timeout_s:
+                raise _lib.NdError(f"inputs-consumed signal stuck at {int(self._input_flag[0])} of {self._batch_calls} batches")
+            time.sleep(2e-5)
+
     def predict_batch(self, cond, images: torch.Tensor, noise: Optional[torch.Tensor], mc: int, T: int, temperature: float,
                       use_graph: bool = True, clone: bool = True) -> Dict[str, torch.Tensor]:
         """classification_train_separately.py:749-794 for one batch in ONE library call (nd_predict_batch; one hipGraph launch
@@ -306,5 +326,7 @@ class EnsembleEngine:
         out = NdBatchOut(ptr(buf["samples"]), ptr(buf["prob"]), ptr(buf["vote"]), ptr(buf["probs"]), ptr(buf["yhat"]))
         check(self.lib.nd_predict_batch(self.h, cond, ptr(buf["images"]), ptr(nz), C.byref(out), B, mc, T, float(temperature),
                                         1 if use_graph else 0, self._stream()), "nd_predict_batch")
+        if getattr(self, "_input_flag", None) is not None:
+            self._batch_calls += 1
         keys = ("samples", "vote", "prob", "probs", "yhat")
         return {k: (buf[k].clone() if clone else buf[k]) for k in keys}

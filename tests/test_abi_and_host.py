@@ -65,6 +65,7 @@ def test_abi_argument_validation_without_gpu():
     assert lib.nd_set_loop_form(h, 2, ctypes.c_float(0.0)) != 0 and b"mode" in lib.nd_last_error()
     assert lib.nd_set_loop_form(h, 1, ctypes.c_float(2e6)) != 0 and lib.nd_set_loop_form(None, 1, ctypes.c_float(0.0)) != 0
     assert lib.nd_persist_status(h, 0) < 0 and b"workspace" in lib.nd_last_error()
+    assert lib.nd_set_input_flag(h, None) < 0 and b"workspace" in lib.nd_last_error()          # needs a bound workspace (it resets a device counter)
     assert lib.nd_skinny_row_fragments(32) == 2 and lib.nd_skinny_row_fragments(70) == 5 and lib.nd_skinny_row_fragments(64) == 4
     assert lib.nd_skinny_row_fragments(16) == 1 and lib.nd_skinny_row_fragments(0) < 0
     assert lib.nd_destroy(h) == 0

@@ -282,11 +282,11 @@ def test_main_test_path_from_image_files_on_disk(tmp_path, capsys, monkeypatch):
         assert key in r.stdout, (key, r.stdout[-1500:])
     # (ii) in-process, the batch loop observed
     seen = {"raw": [], "targets": [], "runner": None}
-    orig_perturb, orig_atk = runner_mod.Diffusion.perturb, runner_mod.Diffusion.test_atk
+    orig_predict, orig_atk = runner_mod.Diffusion.predict_batch, runner_mod.Diffusion.test_atk
 
-    def spy_perturb(self, images_224, lo=0, hi=None, B_total=None):       # what the batch loop uploaded (:722), before :726-737
+    def spy_predict(self, images_224, *a, **kw):                          # what the batch loop uploaded (:722) and hands to the hot path
         seen["raw"].append(images_224.cpu().clone())
-        return orig_perturb(self, images_224, lo, hi, B_total)
+        return orig_predict(self, images_224, *a, **kw)
 
     def spy_atk(self, test_loader=None):
         seen["runner"] = self
@@ -297,7 +297,7 @@ def test_main_test_path_from_image_files_on_disk(tmp_path, capsys, monkeypatch):
         seen["targets"] = [t.clone() for _, t in batches]
         return orig_atk(self, test_loader=batches)
 
-    monkeypatch.setattr(runner_mod.Diffusion, "perturb", spy_perturb)
+    monkeypatch.setattr(runner_mod.Diffusion, "predict_batch", spy_predict)
     monkeypatch.setattr(runner_mod.Diffusion, "test_atk", spy_atk)
     argv = flags + ["--config", ypath, "--exp", os.path.join(str(tmp_path), "results_inproc")]
     assert nd_main.main(argv) == 0

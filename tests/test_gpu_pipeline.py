@@ -67,6 +67,53 @@ def test_conditioner_arena_poisoned_with_nans_changes_no_bit():
         assert torch.equal(a, b)
 
 
+def test_loader_loop_uploads_straight_into_the_input_buffer_and_matches_per_batch_calls():
+    """runner._rank_batches without device-side perturbations: every host batch is copied on a side stream STRAIGHT into the library's
+    input buffer as soon as the previous batch's graph has read it (nd_set_input_flag: a count published to pinned host memory right
+    behind the last kernel that reads the images), i.e. while the previous batch's sampler is still running.  Five DISTINCT batches
+    through test_atk must give exactly the probabilities of five plain predict_batch calls on explicitly uploaded tensors (same seed,
+    same in-library noise sequence): a refill that came too early would corrupt the batch still in flight, one that came too late or
+    skipped the wait for its own copy would feed stale pixels.  Also: the flag has counted every batch, only host bytes of the five
+    batches crossed PCIe, and with a perturbation flag on the loop takes the staged path and still agrees with per-batch calls."""
+    import argparse
+    from nested_diffusion_amd.mapping import Classifier, GuidingConditioner, VisionTransformer
+    from nested_diffusion_amd.runner import Diffusion
+    ns = argparse.Namespace
+    embed, heads, depth, img, patch, K, T, C, B = 128, 2, 5, 32, 16, 5, 6, 2, 6
+    D, H, F = 3 * img * img, 64, 64
+    vp = ref_cpu.init_vit_params(embed=embed, depth=depth, patch=patch, img=img, seed=3)
+    n_tok = (img // patch) ** 2
+    mlps = [ref_cpu.init_classifier_params(n_tok * embed, widths=(64, 32, 16), seed=20 + i) for i in range(K)]
+    members = [ref_cpu.init_cond_model_params(D, H, F, C, T, True, seed=40 + i) for i in range(K)]
+    cfg = ns(data=ns(dataset="ChestXRay", num_classes=C), model=ns(data_dim=D, hidden_dim=H, feature_dim=F, arch="linear"),
+             diffusion=ns(timesteps=T, beta_schedule="linear", beta_start=1e-4, beta_end=0.02, aux_cls=ns(arch="sevit"),
+                          trained_aux_cls_ckpt_path="", trained_diffusion_ckpt_path=[[]], include_guidance=True),
+             testing=ns(batch_size=B))
+    g = torch.Generator().manual_seed(17)
+    batches = [(torch.rand(B, 3, img, img, generator=g), torch.randint(0, C, (B,), generator=g)) for _ in range(5)]
+
+    def make(**flags):
+        cond = GuidingConditioner(VisionTransformer(vp, heads, "cuda"), [Classifier(m, "cuda") for m in mlps])
+        return Diffusion(ns(seed=5, mc_trials=2, **flags), cfg, device="cuda", conditioner=cond, noise_estimator_states=[dict(m) for m in members])
+
+    for flags in ({}, {"brightness": 0.1}):
+        loop = make(**flags)
+        loop.test_atk(test_loader=batches)
+        direct = not flags
+        if direct:
+            torch.cuda.synchronize()
+            assert loop.engine._batch_calls == 5 and int(loop.engine._input_flag[0]) == 5
+        else:
+            assert getattr(loop.engine, "_input_flag", None) is None                 # the staged path never asked for the signal
+        assert loop.bytes_uploaded == 5 * B * 3 * img * img * 4
+        plain = make(**flags)
+        plain.load_noise_estimators(max_batch=B)
+        plain._seed_noise(0)
+        want = torch.cat([plain.predict_batch(plain.perturb(x.cuda()))["prob"] for x, _ in batches])
+        assert torch.equal(loop.last_probs, want), flags
+        assert not torch.equal(want[:B], want[B:2 * B])                               # the batches really differ
+
+
 def test_module_and_p_sample_loop_dropin():
     """ConditionalModel.load_state_dict(reference state) + p_sample_loop / p_sample / p_sample_t_1to0 with
     the reference's signatures reproduce the golden trajectory."""
