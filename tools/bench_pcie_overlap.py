@@ -4,7 +4,9 @@ Variants, all K = 5, T = 100, B = 32 at config dims, same process:
   A  resident: predict_batch on the library's own input buffer (bench.py's timed loop)
   B  + a device-to-device copy of the batch into that buffer per step
   C  B + an independent pinned H2D copy of 19.3 MB on a side stream per step (no dependency: pure overlap cost)
-  D  the runner's loader loop (runner._rank_batches: staging memcpy, side-stream H2D one batch ahead, event wait)
+  D  the runner's loader loop (runner._rank_batches) with pageable batches: staging memcpy + side-stream H2D.  Since nd_set_input_flag the loop
+     copies straight into the library's input buffer once the running batch has read it (no perturbation flags here); the figures kept in
+     profiles/r06_pcie_overlap.txt are those of the earlier staged loop (two device buffers, copy released at the graph boundary) = variant H
   E  D with the batches already pinned (no staging memcpy)
   F / G / H  the synchronisation pieces of D one at a time (see the functions)"""
 import argparse, os, sys, time
