@@ -184,14 +184,6 @@ class Diffusion(object):
         z = torch.randn(K, T, mc, B_total, C, device=self.device)
         return z[:, :, :, lo:hi].reshape(K, T, mc * (hi - lo), C).contiguous()
 
-    def shard_of_batch(self, images_raw: torch.Tensor, lo: int, hi: int) -> torch.Tensor:
-        """Rows [lo, hi) of a HOST batch, uploaded and perturbed (:722-737).  Only the shard crosses PCIe; the random choices of the
-        perturbations are made for the WHOLE batch (perturb), so image i is treated alike at any world size."""
-        B_total = images_raw.shape[0]
-        x = images_raw[lo:hi].to(self.device, torch.float32)
-        self.bytes_uploaded += x.numel() * 4
-        return self.perturb(x, lo, hi, B_total)
-
     def _perturbs(self) -> bool:
         """Does any flag of the robustness protocol change the pixels on the device (perturb: :726-737)?"""
         a = self.args
