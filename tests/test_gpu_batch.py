@@ -433,3 +433,37 @@ def test_probes_do_not_change_results_and_report_intervals():
         assert torch.equal(plain[k], probed[k]), k
     assert torch.equal(r.predict_batch(x, noise=nz)["samples"], plain["samples"])
     assert r.engine.probe_nodes() == 0                            # rebuilt with profiling off: no record node
+
+
+def test_inputs_consumed_count_is_published_per_call_and_replay():
+    """nd_set_input_flag: every nd_predict_batch call -- the eager first call of a shape, graph replays, use_graph = 0 -- stores the count of
+    calls whose input buffer has been read to the caller's pinned host word (right behind the encoder hoist's pack, the last reader of
+    images_dev); results are unchanged by the signal; NULL switches it off; the count restarts with the next flag."""
+    import ctypes
+    K, T, B, mc = 5, 6, 4, 2
+    r, (_, _, _, _, _, img) = _runner(K, T, B, mc)
+    eng = r.engine
+    x = torch.rand(B, 3, img, img, generator=torch.Generator().manual_seed(2)).cuda()
+    nz = torch.randn(K, T, mc * B, 2, generator=torch.Generator().manual_seed(3)).cuda()
+    before = r.predict_batch(x, noise=nz)["prob"]
+    eng.enable_input_flag()
+    assert int(eng._input_flag[0]) == 0
+    outs = [r.predict_batch(x, noise=nz)["prob"] for _ in range(3)]            # eager + recording, then two replays
+    outs.append(r.predict_batch(x, noise=nz, use_graph=False)["prob"])
+    eng.inputs_consumed()                                                       # host wait: returns once the 4th batch has read its inputs
+    torch.cuda.synchronize()
+    assert int(eng._input_flag[0]) == 4 == eng._batch_calls
+    for o in outs:
+        assert torch.equal(o, before)
+    assert eng.lib.nd_set_input_flag(eng.h, None) == 0                          # off: the word stays where it is
+    r.predict_batch(x, noise=nz)
+    torch.cuda.synchronize()
+    assert int(eng._input_flag[0]) == 4
+    word = torch.zeros(1, dtype=torch.int32).pin_memory()
+    assert eng.lib.nd_set_input_flag(eng.h, ctypes.c_void_p(word.data_ptr())) == 0
+    r.predict_batch(x, noise=nz)
+    torch.cuda.synchronize()
+    assert int(word[0]) == 1                                                     # a new flag counts from one
+    assert eng.lib.nd_set_input_flag(eng.h, ctypes.c_void_p(word.data_ptr() + 2)) != 0   # misaligned
+    eng._input_flag = None                                                       # (this test drove the flag by hand)
+    assert eng.lib.nd_set_input_flag(eng.h, None) == 0
