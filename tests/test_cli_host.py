@@ -163,3 +163,18 @@ def test_tensor_key_cannot_be_forged_by_a_recycled_address():
     k = _TensorKey(c)
     c.view(2, 4)[0, 0] = 5                               # ... shared with every view
     assert not k.matches(c)
+
+
+def test_loader_path_selection_follows_the_perturbation_flags():
+    """runner.Diffusion._perturbs: the batch loop uploads straight into the library's input buffer only when no flag of the robustness
+    protocol (test.sh:24: --noise_perturbation, --low_resolution, --brightness, --contrast, --covered, --crop) changes pixels on the
+    device; test.sh's own neutral values (0 / 0 / 0 / 1 / unset / 0) select the direct path."""
+    import argparse
+    from nested_diffusion_amd.runner import Diffusion
+    ns = argparse.Namespace
+    neutral = dict(noise_perturbation=0.0, low_resolution=0, brightness=0.0, contrast=1.0, covered=None, crop=0.0)
+    assert not Diffusion._perturbs(ns(args=ns(**neutral)))
+    assert not Diffusion._perturbs(ns(args=ns()))                                   # flags absent altogether
+    assert not Diffusion._perturbs(ns(args=ns(**{**neutral, "low_resolution": 1, "covered": (0.0, 3.0)})))
+    for k, v in (("noise_perturbation", 0.05), ("low_resolution", 2), ("brightness", -0.2), ("contrast", 0.8), ("covered", (0.1, 2.0)), ("crop", 0.25)):
+        assert Diffusion._perturbs(ns(args=ns(**{**neutral, k: v}))), k
