@@ -692,9 +692,14 @@ extern "C" int nd_load_member(nd_handle h, int k, const nd_member_weights* w, vo
         //   fp16: none  7.67 | 5+0 7.11 | 5+1 6.88 | 5+2 6.96 | all 7.91                                 (a matrix = 34 MB)
         // i.e. ~200 MB is what stays (the rest of the cache turns over with activations, tables and the streamed lines).
         const double mat = (double)F * F * (h->half ? 2.0 : 4.0);
-        const int n_keep = (int)(ND_KEEP_BYTES / mat);
+        const char* keep_mb = getenv("ND_KEEP_MB");                       // experiments: another residency budget (MB)
+        const int n_keep = (int)((keep_mb ? atof(keep_mb) * 1e6 : ND_KEEP_BYTES) / mat);
         ds[L_LIN2].keep = k < n_keep;
         ds[L_LIN3].keep = c.n_members + k < n_keep;
+        if (const char* plan = getenv("ND_KEEP_PLAN")) {                  // experiments: "a,b" = lin2 of members < a, lin3 of members < b
+            int a = 0, b = 0;
+            if (sscanf(plan, "%d,%d", &a, &b) == 2) { ds[L_LIN2].keep = k < a; ds[L_LIN3].keep = k < b; }
+        }
     }
     // small synchronous H2D copies: load time only, never on the sampling path.  The sync also means the
     // caller may release its raw weight tensors as soon as this function returns.
