@@ -134,11 +134,11 @@ __global__ __launch_bounds__(PS_WAVES * 64) void k_persist_loop(PersistArgs args
     const ps_cbytes ka = (ps_cbytes)__builtin_amdgcn_kernarg_segment_ptr();
     const int tid = threadIdx.x, lane = tid & 63, lane4 = lane * 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int F, M, B, T, nm, maxM, spin_ticks;
+    int F, M, B, T, nm, maxM, spin_ticks, fake_res;
     unsigned* bar;
     {
         const PersistScalars S = PS_ARG(ka, PersistScalars, s);
-        F = S.F; M = S.M; B = S.B; T = S.T; nm = S.nm; maxM = S.maxM; spin_ticks = S.spin_ticks; bar = S.bar;
+        F = S.F; M = S.M; B = S.B; T = S.T; nm = S.nm; maxM = S.maxM; spin_ticks = S.spin_ticks; bar = S.bar; fake_res = S.fake_resident;
         const int wpm0 = gridDim.x / nm, g0 = blockIdx.x / wpm0;
         if (g0 >= S.active) return;
         if (S.skew > 0 && g0 > 0) {                       // members start `skew` apart: their phases interleave instead of coinciding
@@ -238,9 +238,9 @@ __global__ __launch_bounds__(PS_WAVES * 64) void k_persist_loop(PersistArgs args
                     for (int mt = 0; mt < MT; ++mt)
                         x[u][mt] = ps_ld16_sc1(rx, lane * 16, ((min(mt, mtiles - 1) * nch + grp * U + u) * 1024));
             };
-            auto LD = [&](float4 (&w)[U][NFA], float4 (&x)[U][MT], int grp) {
+            auto LD = [&](float4 (&w)[U][NFA], float4 (&x)[U][MT], int grp, int grpw) {
                 // the graph form's issue order: per chunk, its weight fragments, then its activation fragments
-                const size_t go = (size_t)grp * U * 256;
+                const size_t go = (size_t)grpw * U * 256;
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
 #pragma unroll
@@ -265,7 +265,8 @@ __global__ __launch_bounds__(PS_WAVES * 64) void k_persist_loop(PersistArgs args
                             }
             };
             auto G = [&](int i) { return min(wave + i * WAVES, glast); };
-            if (ngw > 0) LDW(wA, G(0));                           // weights of the first stage: in flight across the barrier
+            auto GW = [&](int i) { return i < fake_res ? min(wave, glast) : G(i); };   // (timing ablation: see PersistScalars::fake_resident)
+            if (ngw > 0) LDW(wA, GW(0));                          // weights of the first stage: in flight across the barrier
             alive = ps_member_barrier(counter, genw, errw, ++bar_gen, (unsigned)wpm, spin_ticks, s_flag);
             if (!alive) return;
             PS_STAMP(MODE == 0 ? 2 : 5);
@@ -279,10 +280,10 @@ __global__ __launch_bounds__(PS_WAVES * 64) void k_persist_loop(PersistArgs args
             __builtin_amdgcn_sched_barrier(0);
             int i = 0;
             for (; i + 1 < ngw; i += 2) {
-                LD(wB, xB, G(i + 1));
+                LD(wB, xB, G(i + 1), GW(i + 1));
                 MMA(wA, xA);
                 PS_MIX()
-                LD(wA, xA, G(i + 2));
+                LD(wA, xA, G(i + 2), GW(i + 2));
                 MMA(wB, xB);
                 PS_MIX()
             }

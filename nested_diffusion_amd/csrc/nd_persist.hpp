@@ -18,6 +18,9 @@ struct PersistScalars {
     int skew;          // start offset between consecutive members, in ticks of the 100 MHz wall clock (0: all start together)
     int spin_ticks;    // a barrier wait longer than this sets the error word and the workgroup leaves the kernel
     int active;        // members that run (experiments: ND_PERSIST_ACTIVE; the others' workgroups leave at once, their outputs are not written)
+    int fake_resident; // TIMING ABLATION ONLY (ND_PERSIST_FAKE_RESIDENT = n, results are WRONG): the weight loads of the first n of a wave's
+                       // register stages per layer all go to the wave's FIRST stage (cache hits instead of fabric traffic) -- an upper bound on
+                       // what holding that share of the weights on chip could buy, with the instruction stream and the MFMAs unchanged
 };
 
 struct PersistArgs {                         // by value in the kernel arguments, read through the constant address space

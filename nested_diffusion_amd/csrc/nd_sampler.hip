@@ -1051,8 +1051,9 @@ static hipError_t emit_loop(nd_handle_s* h, Emitter& em, int m0, int nm, StepIO 
             pa.io = io;
             const char* act = getenv("ND_PERSIST_ACTIVE");                  // experiments only: run the first n members of the launch
             const char* spin = getenv("ND_PERSIST_SPIN_TICKS");             // tests only: how long a barrier wait may last (100 MHz ticks)
+            const char* fake = getenv("ND_PERSIST_FAKE_RESIDENT");          // timing ablation only: results are wrong (nd_persist.hpp)
             pa.s = PersistScalars{h->persist_bar, nm, B, M, maxM, F, T, h->persist_skew_ticks, spin ? atoi(spin) : 100000000 /* 1 s */,
-                                  act ? atoi(act) : nm};
+                                  act ? atoi(act) : nm, fake ? atoi(fake) : 0};
             note_h_layout(h, m0, nm, false);
             hipEvent_t* ev = nullptr;
             if (h->profiling) {
