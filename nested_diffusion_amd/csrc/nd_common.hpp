@@ -342,10 +342,15 @@ __global__ __launch_bounds__(WAVES * 64) void k_skinny(SkinnyInline di, const Sk
         float4 wA[U][NFA], xA[U][MT], wB[U][NFA], xB[U][MT];
         auto LD = [&](float4 (&w)[U][NFA], float4 (&x)[U][MT], int grp) {
             const size_t go = (size_t)grp * U * 256;
+#ifdef ND_SKINNY_ABLATE_W      // timing ablation only (variant library; results WRONG): every weight load of a wave goes to its FIRST register stage
+            const size_t gow = (size_t)min(wave, glast) * U * 256;     // -- cache hits instead of fabric traffic, same instructions, same MFMAs
+#else
+            const size_t gow = go;
+#endif
 #pragma unroll
             for (int u = 0; u < U; ++u) {
 #pragma unroll
-                for (int f = 0; f < NFA; ++f) w[u][f] = nd_ld16<NTV>(wp[f] + go + u * 256 + lane4);
+                for (int f = 0; f < NFA; ++f) w[u][f] = nd_ld16<NTV>(wp[f] + gow + u * 256 + lane4);
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) x[u][mt] = nd_ld16<false>(xp[mt] + go + u * 256 + lane4);
             }
