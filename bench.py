@@ -379,6 +379,12 @@ def main():
         # so the kernel sits against BOTH the stream and the f32 matrix pipe (PMC SQ_VALU_MFMA_BUSY 0.55, profiles/r02_pmc_mfma.csv)
         roof["co_limit_mfma_frac"] = (K * 2.0 * M * F * F / (avg_us * 1e-6) / 1e12 / F32_MFMA_PEAK_TF) if (n_probe and args.dtype == "f32") else None
         roof["traffic_source"] = why
+        if args.dtype == "f32" and K == 5 and M == 32:
+            # REPLAYED, like `traffic`: a timing ablation of this very shape (variant library, every weight load of k_skinny served from
+            # cache, same instructions and MFMAs) -- what the launch would take with unlimited bandwidth for the weights
+            roof["launch_us_with_weights_from_cache"] = {"value": 50.8, "source": "profiles/r06_skinny_weight_traffic_ablation.txt (50.3-51.3 us against "
+                                                        "57.2-57.8 on that box): the weight bytes are worth 1.12 x; the rest is the six-fragment workgroups' "
+                                                        "exact-f32 MFMAs (45 us at 2.4 GHz), ramp and epilogue"}
     else:
         # M = B*mc rows > 128: the blocks are compute-bound GEMMs (2*M*F*F flop per member and launch).  fp32 arithmetic runs on the
         # bf16 matrix pipe with exact products (nine bf16 pair products per fp32 product, csrc/nd_b9.hpp): the peak for USEFUL fp32
